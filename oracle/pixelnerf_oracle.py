@@ -1,0 +1,234 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement (PyTorch-CPU tensor ops, fp32) of the reference's
+per-ray hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this file; the product (pixel_nerf_multiscale_amd/) never does and fails loudly without its HIP library.
+
+Pinned: tests/test_oracle_golden.py checks every function below against the fixtures in
+tests/golden/*.npz, which tools/gen_golden.py produced by running the reference itself
+(src/render/nerf.py + src/model/models.py.backup2 + encoder.py + resnetfc.py + code.py, unmodified)
+in the dev container.  The reference has no tests/golden vectors of its own for this path.
+
+Every random draw is an explicit argument (the reference draws from torch's global generator:
+nerf.py:111,135,141,158), in the reference's draw order:
+    noise_c (N,Kc)  u (N,Kf-Kfd)  r (N,Kf-Kfd)  g (N,Kfd)
+
+Each function cites the reference lines it restates (paths relative to /root/reference/src).
+"""
+import math
+
+import torch
+
+
+# ------------------------------------------------------------------ a2  render/nerf.py:98-118
+def sample_coarse(rays, n_coarse, lindisp, noise_c):
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    step = 1.0 / n_coarse
+    z_steps = torch.linspace(0, 1 - step, n_coarse, dtype=torch.float32)[None].repeat(rays.shape[0], 1)
+    z_steps = z_steps + noise_c * step
+    if not lindisp:
+        return near * (1 - z_steps) + far * z_steps
+    return 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+
+
+# ------------------------------------------------------------------ a4  render/nerf.py:178-182,223-249
+def composite(rays, z_samp, out, white_bkgd):
+    """out (N,K,4) = model output [rgb, sigma]; returns weights (N,K), rgb (N,3), depth (N)."""
+    deltas = z_samp[:, 1:] - z_samp[:, :-1]
+    delta_inf = rays[:, 7:8] - z_samp[:, -1:]
+    deltas = torch.cat([deltas, delta_inf], -1)
+    rgbs, sigmas = out[..., :3], out[..., 3]
+    alphas = 1 - torch.exp(-deltas * torch.relu(sigmas))
+    alphas_shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    T = torch.cumprod(alphas_shifted, -1)
+    weights = alphas * T[:, :-1]
+    rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+    depth = torch.sum(weights * z_samp, -1)
+    if white_bkgd:
+        rgb = rgb + 1 - weights.sum(dim=1).unsqueeze(-1)
+    return weights, rgb, depth
+
+
+# ------------------------------------------------------------------ a5  render/nerf.py:120-148
+def sample_fine(rays, weights, n_coarse, lindisp, u, r):
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)           # (N, Kc+1)
+    # searchsorted(right=True) - 1 = (number of cdf entries <= u) - 1, clamped below only
+    inds = (cdf[:, None, :] <= u[:, :, None]).sum(-1).float() - 1.0
+    inds = torch.clamp_min(inds, 0.0)
+    z_steps = (inds + r) / n_coarse
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    if not lindisp:
+        return near * (1 - z_steps) + far * z_steps
+    return 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+
+
+# ------------------------------------------------------------------ a6  render/nerf.py:150-161
+def sample_fine_depth(rays, depth, depth_std, g):
+    z = depth[:, None] + g * depth_std
+    return torch.max(torch.min(z, rays[:, 7:8]), rays[:, 6:7])
+
+
+# ------------------------------------------------------------------ a9  model/models.py.backup2:108-150
+def encode_cameras(poses_c2w, focal, c, W, H):
+    """poses (SB,NS,4,4) c2w -> w2c (SB*NS,3,4); focal -> (1|SB*NS,2) with fy negated; c -> (1|SB*NS,2)."""
+    poses = poses_c2w.reshape(-1, 4, 4)
+    rot = poses[:, :3, :3].transpose(1, 2)
+    trans = -torch.bmm(rot, poses[:, :3, 3:])
+    w2c = torch.cat((rot, trans), dim=-1)
+    focal = torch.as_tensor(focal, dtype=torch.float32)
+    if focal.ndim == 0:
+        focal = focal[None, None].repeat(1, 2)
+    elif focal.ndim == 1:
+        focal = focal.unsqueeze(-1).repeat(1, 2)
+    else:
+        focal = focal.clone()
+    focal = focal.float().clone()
+    focal[..., 1] *= -1.0
+    if c is None:
+        c = torch.tensor([[W * 0.5, H * 0.5]], dtype=torch.float32)
+    else:
+        c = torch.as_tensor(c, dtype=torch.float32)
+        if c.ndim == 0:
+            c = c[None, None].repeat(1, 2)
+        elif c.ndim == 1:
+            c = c.unsqueeze(-1).repeat(1, 2)
+    return w2c, focal, c
+
+
+# ------------------------------------------------------------------ a11 model/code.py:11-46
+def positional_encoding(x, num_freqs=6, freq_factor=1.5):
+    """[x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...], f_k = freq_factor * 2^k; pi/2 in fp32."""
+    freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
+    fr = torch.repeat_interleave(freqs, 2).view(1, -1, 1)
+    ph = torch.zeros(2 * num_freqs)
+    ph[1::2] = math.pi * 0.5
+    ph = ph.view(1, -1, 1)
+    embed = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
+    embed = torch.sin(torch.addcmul(ph, embed, fr))
+    return torch.cat((x, embed.view(x.shape[0], -1)), dim=-1)
+
+
+# ------------------------------------------------------------------ a12 model/encoder.py:138-205 (+ ATen grid_sampler_2d)
+def index_latent(uv, latents):
+    """uv (B,P,2) in IMAGE pixels; latents = list of (B,C,H,W).  Bilinear / align_corners=True /
+    border padding, uv normalised by each level's OWN size: the texel coordinate equals the
+    pixel coordinate clamped to [0,W-1]x[0,H-1].  Written out tap by tap (no F.grid_sample) following
+    ATen's grid_sampler_2d: unnormalise ((g+1)/2)*(size-1), clip, floor, 4 in-bounds taps."""
+    outs = []
+    for lat in latents:
+        B, C, H, W = lat.shape
+        if uv.shape[0] == 1 and B > 1:
+            uvb = uv.expand(B, -1, -1)
+        else:
+            uvb = uv
+        gx = (uvb[:, :, 0] / (W - 1)) * 2 - 1
+        gy = (uvb[:, :, 1] / (H - 1)) * 2 - 1
+        ix = ((gx + 1) / 2) * (W - 1)
+        iy = ((gy + 1) / 2) * (H - 1)
+        ix = torch.clamp(ix, 0, W - 1)      # NaN propagates, like ATen's clip via min/max
+        iy = torch.clamp(iy, 0, H - 1)
+        x0 = torch.floor(ix); y0 = torch.floor(iy)
+        x1 = x0 + 1; y1 = y0 + 1
+        w_nw = (x1 - ix) * (y1 - iy)
+        w_ne = (ix - x0) * (y1 - iy)
+        w_sw = (x1 - ix) * (iy - y0)
+        w_se = (ix - x0) * (iy - y0)
+        flat = lat.reshape(B, C, H * W)
+        acc = torch.zeros(B, C, uvb.shape[1], dtype=lat.dtype)
+        for xx, yy, ww in ((x0, y0, w_nw), (x1, y0, w_ne), (x0, y1, w_sw), (x1, y1, w_se)):
+            inb = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+            xi = torch.where(inb, xx, torch.zeros_like(xx)).long()
+            yi = torch.where(inb, yy, torch.zeros_like(yy)).long()
+            idx = (yi * W + xi)[:, None, :].expand(-1, C, -1)
+            tap = torch.gather(flat, 2, idx)
+            acc = acc + torch.where(inb[:, None, :], tap * ww[:, None, :], torch.zeros_like(tap))
+        outs.append(acc)
+    return torch.cat(outs, dim=1)            # (B, sum C, P)
+
+
+# ------------------------------------------------------------------ a13/a14 model/resnetfc.py:53-62,173-236 ; util/util.py:466-476
+def resnetfc(sd, zx, d_latent, NS, P, n_blocks=5, combine_layer=3, combine_type="average"):
+    """sd = state-dict (reference key names).  zx (SB*NS*P, d_latent + d_in) -> (SB*P, d_out)."""
+    lin = lambda x, k: torch.addmm(sd[k + ".bias"], x, sd[k + ".weight"].t())
+    z, x = zx[:, :d_latent], zx[:, d_latent:]
+    x = lin(x, "lin_in")
+    for b in range(n_blocks):
+        if b == combine_layer and NS > 1:
+            x = x.reshape(-1, NS, P, x.shape[-1])
+            x = x.mean(dim=1) if combine_type == "average" else x.max(dim=1)[0]
+            x = x.reshape(-1, x.shape[-1])
+        if d_latent > 0 and b < combine_layer:
+            x = x + lin(z, f"lin_z.{b}")
+        net = lin(torch.relu(x), f"blocks.{b}.fc_0")
+        dx = lin(torch.relu(net), f"blocks.{b}.fc_1")
+        x = x + dx
+    return lin(torch.relu(x), "lin_out")
+
+
+# ------------------------------------------------------------------ a10/a15 model/models.py.backup2:155-282
+def point_forward(sd, cam, latents, xyz, viewdirs, NS, use_code_viewdirs=False,
+                  n_blocks=5, combine_layer=3, combine_type="average", return_stages=False):
+    """xyz, viewdirs (SB,P,3) world space -> (SB,P,4) [sigmoid rgb, relu sigma].
+    cam = (w2c (SB*NS,3,4), focal (1|SB*NS,2), c (1|SB*NS,2)) from encode_cameras."""
+    w2c, focal, c = cam
+    SB, P, _ = xyz.shape
+    rep = lambda t: t.unsqueeze(1).expand(-1, NS, *t.shape[1:]).reshape(-1, *t.shape[1:])
+    x = rep(xyz)                                                     # (SB*NS,P,3)
+    x_rot = torch.matmul(w2c[:, None, :3, :3], x.unsqueeze(-1))[..., 0]
+    x_cam = x_rot + w2c[:, None, :3, 3]
+    zf = x_rot.reshape(-1, 3)                                        # normalize_z, use_xyz
+    vd = torch.matmul(w2c[:, None, :3, :3], rep(viewdirs.reshape(SB, P, 3, 1))).reshape(-1, 3)
+    if use_code_viewdirs:
+        zf = positional_encoding(torch.cat((zf, vd), dim=1))
+    else:
+        zf = torch.cat((positional_encoding(zf), vd), dim=1)
+    uv = -x_cam[:, :, :2] / x_cam[:, :, 2:]
+    uv = uv * (rep(focal.unsqueeze(1)) if focal.shape[0] > 1 else focal.unsqueeze(1))
+    uv = uv + (rep(c.unsqueeze(1)) if c.shape[0] > 1 else c.unsqueeze(1))
+    lat = index_latent(uv, latents)                                  # (SB*NS, L, P)
+    L = lat.shape[1]
+    lat = lat.transpose(1, 2).reshape(-1, L)
+    zx = torch.cat((lat, zf), dim=-1)
+    o = resnetfc(sd, zx, L, NS, P, n_blocks, combine_layer, combine_type).reshape(-1, P, 4)
+    out = torch.cat([torch.sigmoid(o[..., :3]), torch.relu(o[..., 3:4])], dim=-1).reshape(SB, P, 4)
+    if return_stages:
+        return out, dict(uv=uv, index_out=lat, mlp_in=zx, mlp_out=o.reshape(-1, 4))
+    return out
+
+
+# ------------------------------------------------------------------ a1/a3/a7/a8 render/nerf.py:163-221,251-316
+def render(sd_coarse, sd_fine, cam, latents, rays, NS, n_coarse, n_fine, n_fine_depth, depth_std,
+           white_bkgd, lindisp, noise, use_code_viewdirs=False, n_blocks=5, combine_layer=3,
+           combine_type="average"):
+    """rays (SB,B,8).  noise = dict(noise_c, u, r, g) (entries for absent stages may be missing).
+    Returns dict(coarse=dict(rgb,depth,weights,z), fine=...) with (SB,B,..) shapes."""
+    SB = rays.shape[0]
+    r = rays.reshape(-1, 8)
+    kw = dict(use_code_viewdirs=use_code_viewdirs, n_blocks=n_blocks, combine_layer=combine_layer,
+              combine_type=combine_type)
+
+    def run(z, sd):
+        K = z.shape[1]
+        pts = (r[:, None, :3] + z.unsqueeze(2) * r[:, None, 3:6]).reshape(SB, -1, 3)
+        dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(SB, -1, 3)
+        out = point_forward(sd, cam, latents, pts, dirs, NS, **kw).reshape(-1, K, 4)
+        w, rgb, depth = composite(r, z, out, white_bkgd)
+        return w, rgb, depth, out
+
+    z_c = sample_coarse(r, n_coarse, lindisp, noise["noise_c"])
+    w, rgb, depth, out_c = run(z_c, sd_coarse)
+    fmt = lambda w, rgb, depth, z, o: dict(rgb=rgb.reshape(SB, -1, 3), depth=depth.reshape(SB, -1),
+                                           weights=w.reshape(SB, -1, w.shape[-1]), z=z, pts_out=o)
+    res = dict(coarse=fmt(w, rgb, depth, z_c, out_c))
+    if n_fine > 0:
+        samps = [z_c]
+        if n_fine - n_fine_depth > 0:
+            samps.append(sample_fine(r, w, n_coarse, lindisp, noise["u"], noise["r"]))
+        if n_fine_depth > 0:
+            samps.append(sample_fine_depth(r, depth, depth_std, noise["g"]))
+        z_f, _ = torch.sort(torch.cat(samps, dim=-1), dim=-1)
+        w2, rgb2, depth2, out_f = run(z_f, sd_fine if sd_fine is not None else sd_coarse)
+        res["fine"] = fmt(w2, rgb2, depth2, z_f, out_f)
+    return res

@@ -1,0 +1,48 @@
+"""Glue between fixtures (tests/golden) and the oracle restatement (oracle/)."""
+import numpy as np
+import torch
+
+import golden_util as gu
+from oracle import pixelnerf_oracle as orc
+
+
+def noise_from_fixture(fx):
+    """Map the recorded draws (reference draw order, nerf.py:111,135,141,158) to named noise."""
+    order = str(fx["noise_order"]).split(",")
+    spec = fx["spec"]
+    n_imp = spec["Kf"] - spec["Kfd"]
+    names = ["noise_c"]
+    if spec["Kf"] > 0:
+        if n_imp > 0:
+            names += ["u", "r"]
+        if spec["Kfd"] > 0:
+            names += ["g"]
+    assert len(names) == len(order), (names, order)
+    return {n: torch.from_numpy(fx[f"noise{i}_{k}"]) for i, (n, k) in enumerate(zip(names, order))}
+
+
+def oracle_setup(fx):
+    spec = fx["spec"]
+    W, H = spec["image"]
+    cam = orc.encode_cameras(torch.from_numpy(fx["poses"]), spec["focal"], None, W, H)
+    lat = [torch.from_numpy(x) for x in gu.make_latents(spec)]
+    sd_c = {k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, "coarse").items()}
+    sd_f = {k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, "fine").items()} if spec["fine_mlp"] else None
+    return spec, cam, lat, sd_c, sd_f
+
+
+def oracle_render(fx):
+    spec, cam, lat, sd_c, sd_f = oracle_setup(fx)
+    return orc.render(sd_c, sd_f, cam, lat, torch.from_numpy(fx["rays"]), spec["NS"], spec["Kc"], spec["Kf"],
+                      spec["Kfd"], spec["depth_std"], spec["white_bkgd"], spec["lindisp"],
+                      noise_from_fixture(fx), use_code_viewdirs=spec["use_code_viewdirs"],
+                      n_blocks=spec["n_blocks"], combine_layer=spec["combine_layer"],
+                      combine_type=spec["combine_type"])
+
+
+def maxdiff(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a - b)
+    d[both_nan] = 0
+    return float(np.nanmax(d)) if not np.isnan(d).any() else float("nan")
