@@ -1,0 +1,195 @@
+/*
+ * pnr.h — C ABI of libpnr_hip.so, the MI355X (gfx950) native pixelNeRF render hot path.
+ *
+ * The reference (Zxhh123/pixel-nerf-multiscale) is pure Python and has NO native interface; this header
+ * is the boundary a maintainer would bind with ctypes.  Each entry point names
+ * the reference code it replaces (paths relative to the reference's src/).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors' data_ptr()), fp32,
+ *    contiguous, row-major, unless stated otherwise; the library never allocates or frees device
+ *    memory and keeps no mutable global state.
+ *  - `stream` is a hipStream_t (0 = default stream).  Every call is asynchronous on it and
+ *    never synchronises the host.
+ *  - return: 0 ok; <0 PNR_E_* (bad argument / unsupported configuration); >0 a hipError_t.
+ */
+#ifndef PNR_H
+#define PNR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_VERSION 100          /* 0.1.0 */
+#define PNR_MAX_LEVELS 5         /* encoder levels of a multi-scale latent (encoder.py:62-73) */
+#define PNR_MAX_BLOCKS 8         /* ResnetFC blocks (resnetfc.py:147) */
+
+enum {
+    PNR_OK = 0,
+    PNR_E_NULL = -1,             /* required pointer is NULL */
+    PNR_E_SHAPE = -2,            /* inconsistent / out-of-range sizes */
+    PNR_E_UNSUPPORTED = -3,      /* configuration the kernels do not implement */
+    PNR_E_WORKSPACE = -4,        /* workspace too small */
+    PNR_E_ALIGN = -5,            /* pointer not 16-byte aligned where required */
+    PNR_E_PACKED = -6            /* packed weights / latents missing or of the wrong kind */
+};
+
+enum { PNR_F32 = 0, PNR_BF16 = 1, PNR_F16 = 2 };      /* arithmetic type of the fc layers */
+enum { PNR_COMBINE_AVERAGE = 0, PNR_COMBINE_MAX = 1 }; /* util.combine_interleaved (util.py:466-476) */
+
+/* ResnetFC parameters (resnetfc.py:128-158), PyTorch nn.Linear layout: weight (out,in), y = x W^T + b.
+ * State-dict keys: lin_in, lin_z.{b}, blocks.{b}.fc_0 / fc_1, lin_out.  use_spade / softplus (beta>0)
+ * are not supported (no shipped config uses them). */
+typedef struct pnr_mlp {
+    int32_t d_in;                /* 42 = 39 pos-enc + 3 viewdirs, or 78 with use_code_viewdirs */
+    int32_t d_latent;            /* 256 single-scale, 512 multi-scale; sum of level channels */
+    int32_t d_hidden;            /* 512 in every shipped config; MFMA path requires 512 */
+    int32_t d_out;               /* 4 */
+    int32_t n_blocks;            /* 5 */
+    int32_t combine_layer;       /* 3: views are reduced before this block; lin_z exists for b < min(combine_layer, n_blocks) */
+    int32_t combine_type;        /* PNR_COMBINE_* */
+    int32_t reserved0;
+    const float* lin_in_w;  const float* lin_in_b;
+    const float* lin_z_w[PNR_MAX_BLOCKS];  const float* lin_z_b[PNR_MAX_BLOCKS];
+    const float* fc0_w[PNR_MAX_BLOCKS];    const float* fc0_b[PNR_MAX_BLOCKS];
+    const float* fc1_w[PNR_MAX_BLOCKS];    const float* fc1_b[PNR_MAX_BLOCKS];
+    const float* lin_out_w; const float* lin_out_b;
+    /* produced once by pnr_pack_mlp(); required when precision != PNR_F32 */
+    const void* packed;
+    uint64_t packed_bytes;
+    int32_t packed_dtype;        /* PNR_BF16 / PNR_F16 */
+    int32_t reserved1;
+} pnr_mlp;
+
+/* What PixelNeRFNet.encode() leaves on the module (models.py.backup2:108-150) + the encoder's latent
+ * map(s) (encoder.py:106-136).  View index = obj * n_views + v (repeat_interleave order, util.py:58-65). */
+typedef struct pnr_views {
+    int32_t n_objs;              /* SB */
+    int32_t n_views;             /* NS per object */
+    const float* w2c;            /* (SB*NS, 3, 4) [R^T | -R^T t] */
+    const float* focal;          /* (n_focal, 2): fx, fy with fy ALREADY negated (backup2:139) */
+    const float* c;              /* (n_c, 2) principal point */
+    int32_t n_focal;             /* 1 (broadcast) or SB*NS */
+    int32_t n_c;                 /* 1 (broadcast) or SB*NS */
+    int32_t n_levels;            /* 1 = single-scale */
+    int32_t reserved0;
+    const float* latent[PNR_MAX_LEVELS];   /* (SB*NS, C_i, H_i, W_i) NCHW fp32, reference layout */
+    int32_t lat_c[PNR_MAX_LEVELS];
+    int32_t lat_h[PNR_MAX_LEVELS];
+    int32_t lat_w[PNR_MAX_LEVELS];
+    /* produced once per encode() by pnr_pack_latents(); required when precision != PNR_F32:
+     * per level (SB*NS, H_i, W_i, C_i) channels-last in packed_dtype */
+    const void* latent_packed;
+    uint64_t latent_packed_bytes;
+    int32_t packed_dtype;
+    int32_t reserved1;
+} pnr_views;
+
+/* NeRFRenderer attributes (render/nerf.py:62-96) + the PixelNeRFNet switches the kernels need. */
+typedef struct pnr_params {
+    int32_t n_coarse;            /* Kc */
+    int32_t n_fine;              /* Kf (0 = coarse pass only) */
+    int32_t n_fine_depth;        /* Kfd <= Kf */
+    int32_t white_bkgd;
+    int32_t lindisp;
+    int32_t use_code_viewdirs;   /* positional-encode [xyz, viewdirs] together (backup2:207-209) */
+    int32_t num_freqs;           /* 6 (code.py:11) */
+    int32_t precision;           /* PNR_F32 | PNR_BF16 | PNR_F16 */
+    float depth_std;
+    float freq_factor;           /* 1.5 (conf/default.conf:18) */
+    int32_t reserved[6];
+} pnr_params;
+
+/* Explicit random draws, reference order (render/nerf.py:111,135,141,158).  A NULL member (or a NULL
+ * struct) selects the in-kernel counter-based generator keyed by (seed, global ray index). */
+typedef struct pnr_noise {
+    const float* noise_c;        /* (N, Kc)      U[0,1) */
+    const float* u;              /* (N, Kf-Kfd)  U[0,1) */
+    const float* r;              /* (N, Kf-Kfd)  U[0,1) */
+    const float* g;              /* (N, Kfd)     N(0,1) */
+} pnr_noise;
+
+/* Outputs of NeRFRenderer.forward (render/nerf.py:278-303); any member may be NULL. */
+typedef struct pnr_outputs {
+    float* coarse_rgb;           /* (N,3) */
+    float* coarse_depth;         /* (N)   */
+    float* coarse_weights;       /* (N,Kc) */
+    float* fine_rgb;             /* (N,3) */
+    float* fine_depth;           /* (N)   */
+    float* fine_weights;         /* (N,Kc+Kf) */
+    float* z_coarse;             /* (N,Kc)    sampled depths (debug / tests) */
+    float* z_fine;               /* (N,Kc+Kf) sorted */
+} pnr_outputs;
+
+int32_t pnr_version(void);
+const char* pnr_error_string(int32_t code);
+
+/* ---- one-time packing ------------------------------------------------------------------------ */
+/* Repack an MLP's fp32 weights into the fragment stream the MFMA kernel consumes in order
+ * (bf16 or fp16; biases folded in).  `out` must hold pnr_packed_mlp_bytes() bytes, 16-B aligned. */
+uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
+int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
+/* Channels-last low-precision copy of the latent maps for the MFMA kernel's gather. */
+uint64_t pnr_packed_latent_bytes(const pnr_views* views);
+int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
+
+/* ---- stage entry points (also what the tests call) ------------------------------------------- */
+/* NeRFRenderer.sample_coarse (render/nerf.py:98-118).  rays (N,8) -> z (N,Kc). */
+int32_t pnr_sample_coarse(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp,
+                          const float* noise_c, uint64_t seed, int64_t ray_index_base,
+                          float* z_out, void* stream);
+
+/* NeRFRenderer.composite, compositing half (render/nerf.py:178-182,223-249).
+ * rgbsigma (N,K,4) model output -> weights (N,K) [nullable], rgb (N,3), depth (N). */
+int32_t pnr_composite(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays, int32_t K,
+                      int32_t white_bkgd, float* weights_out, float* rgb_out, float* depth_out, void* stream);
+
+/* sample_fine + sample_fine_depth + cat + sort (render/nerf.py:120-161,285-295).
+ * -> z_out (N, Kc + n_fine) ascending. */
+int32_t pnr_sample_fine(const float* rays, const float* z_coarse, const float* weights, const float* depth,
+                        int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
+                        float depth_std, int32_t lindisp, const float* u, const float* r, const float* g,
+                        uint64_t seed, int64_t ray_index_base, float* z_out, void* stream);
+
+/* PixelNeRFNet.forward (models.py.backup2:155-282): world points -> (r,g,b,sigma).
+ * Two ways to name the points:
+ *   rays != NULL: point (ray i, sample k) = o_i + z[i,k] d_i, viewdir d_i  (render/nerf.py:185,204);
+ *                 n_points = n_rays*K, out (n_rays, K, 4)
+ *   rays == NULL: explicit xyz / viewdirs (SB, P, 3); n_points = SB*P, out (SB, P, 4)
+ * points_per_obj = points per object (n_points / views->n_objs). */
+int32_t pnr_point_mlp(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                      const float* rays, const float* z, int32_t K,
+                      const float* xyz, const float* viewdirs,
+                      int64_t n_points, int64_t points_per_obj,
+                      float* out, void* workspace, uint64_t workspace_bytes, void* stream);
+
+/* ---- the whole path: NeRFRenderer.forward with a PixelNeRFNet model (render/nerf.py:251-303) --- */
+/* rays (N,8), N = SB*B, rays_per_obj = B.  fine may be NULL (mlp_fine=None -> coarse MLP, backup2:258). */
+uint64_t pnr_workspace_bytes(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                             int64_t n_rays);
+int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
+                   const pnr_views* views, const float* rays, int64_t n_rays, int64_t rays_per_obj,
+                   const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
+                   const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream);
+
+/* util.gen_rays for one camera (util/util.py:118-148,243-281): pixels [pix0, pix0+n) of a W x H pinhole image. */
+int32_t pnr_gen_rays(const float* c2w /* host, 16 floats */, int32_t W, int32_t H, float fx, float fy,
+                     float cx, float cy, float z_near, float z_far, int64_t pix0, int64_t n,
+                     float* rays_out, void* stream);
+
+/* Timing hook for bench.py: microseconds between the first and last point-MLP launch of the most recent
+ * pnr_render on this thread is NOT kept (no global state); instead the caller brackets calls with
+ * hipEvents on `stream`.  These two helpers expose hipEvent timing on an arbitrary hipStream_t to
+ * ctypes callers (torch.cuda.Event only sees torch's current stream). */
+int32_t pnr_event_create(void** ev);
+int32_t pnr_event_record(void* ev, void* stream);
+int32_t pnr_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int32_t pnr_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNR_H */

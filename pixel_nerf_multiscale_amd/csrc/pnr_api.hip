@@ -1,0 +1,190 @@
+// C-ABI entry points: argument validation, workspace carving, stage sequencing on the caller's stream.
+#include "pnr_common.h"
+
+namespace pnr {
+// point_f32.hip
+uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
+int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
+                  int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+// point_mfma.hip
+uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
+int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
+                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+}  // namespace pnr
+
+using namespace pnr;
+
+static inline uint64_t align256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
+
+extern "C" int32_t pnr_version(void) { return PNR_VERSION; }
+
+extern "C" const char* pnr_error_string(int32_t code) {
+    switch (code) {
+        case PNR_OK: return "ok";
+        case PNR_E_NULL: return "required pointer is NULL";
+        case PNR_E_SHAPE: return "inconsistent or out-of-range sizes";
+        case PNR_E_UNSUPPORTED: return "unsupported configuration";
+        case PNR_E_WORKSPACE: return "workspace too small";
+        case PNR_E_ALIGN: return "pointer must be 16-byte aligned";
+        case PNR_E_PACKED: return "packed weights/latents missing or of the wrong dtype";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+static int32_t check_model(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw) {
+    if (!prm || !mlp || !vw) return PNR_E_NULL;
+    if (!mlp->lin_in_w || !mlp->lin_in_b || !mlp->lin_out_w || !mlp->lin_out_b) return PNR_E_NULL;
+    if (mlp->d_out != 4 || mlp->d_hidden <= 0 || mlp->n_blocks < 1 || mlp->n_blocks > PNR_MAX_BLOCKS) return PNR_E_SHAPE;
+    if (mlp->combine_type != PNR_COMBINE_AVERAGE && mlp->combine_type != PNR_COMBINE_MAX) return PNR_E_UNSUPPORTED;
+    if (prm->num_freqs < 1 || prm->num_freqs > 16) return PNR_E_SHAPE;
+    int d_in = prm->use_code_viewdirs ? 6 + 12 * prm->num_freqs : 3 + 6 * prm->num_freqs + 3;
+    if (mlp->d_in != d_in) return PNR_E_SHAPE;
+    if (vw->n_objs < 1 || vw->n_views < 1 || !vw->w2c || !vw->focal || !vw->c) return PNR_E_NULL;
+    int nv = vw->n_objs * vw->n_views;
+    if ((vw->n_focal != 1 && vw->n_focal != nv) || (vw->n_c != 1 && vw->n_c != nv)) return PNR_E_SHAPE;
+    if (vw->n_levels < 1 || vw->n_levels > PNR_MAX_LEVELS) return PNR_E_SHAPE;
+    int L = 0;
+    for (int i = 0; i < vw->n_levels; ++i) {
+        if (!vw->latent[i]) return PNR_E_NULL;
+        if (vw->lat_c[i] < 1 || vw->lat_h[i] < 2 || vw->lat_w[i] < 2) return PNR_E_SHAPE;  // (W-1) divides uv
+        L += vw->lat_c[i];
+    }
+    if (L != mlp->d_latent) return PNR_E_SHAPE;
+    int n_lin_z = mlp->combine_layer < mlp->n_blocks ? mlp->combine_layer : mlp->n_blocks;
+    if (n_lin_z < 0) return PNR_E_SHAPE;
+    for (int b = 0; b < mlp->n_blocks; ++b) {
+        if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
+        if (b < n_lin_z && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
+    }
+    if (vw->n_views > 1 && mlp->combine_layer >= mlp->n_blocks) return PNR_E_UNSUPPORTED;
+    if (prm->precision != PNR_F32 && prm->precision != PNR_BF16 && prm->precision != PNR_F16) return PNR_E_UNSUPPORTED;
+    return PNR_OK;
+}
+
+static uint64_t point_workspace_bytes(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw) {
+    return prm->precision == PNR_F32 ? point_f32_workspace_bytes(mlp, vw) : point_mfma_workspace_bytes(mlp, vw);
+}
+
+static int32_t point_dispatch(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src,
+                              int64_t n_points, int64_t pts_per_obj, float* out, void* ws, uint64_t ws_bytes,
+                              hipStream_t s) {
+    if (n_points == 0) return PNR_OK;
+    if (prm->precision == PNR_F32) return point_f32(prm, mlp, vw, src, n_points, pts_per_obj, out, ws, ws_bytes, s);
+    return point_mfma(prm, mlp, vw, src, n_points, pts_per_obj, out, ws, ws_bytes, s);
+}
+
+extern "C" int32_t pnr_point_mlp(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                 const float* rays, const float* z, int32_t K, const float* xyz,
+                                 const float* viewdirs, int64_t n_points, int64_t points_per_obj, float* out,
+                                 void* workspace, uint64_t workspace_bytes, void* stream) {
+    int32_t rc = check_model(params, mlp, views);
+    if (rc) return rc;
+    if (!out) return PNR_E_NULL;
+    if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    PointSrc src{};
+    if (rays) {
+        if (!z || K <= 0) return PNR_E_NULL;
+        src.rays = rays; src.z = z; src.K = K;
+        if (n_points % K != 0) return PNR_E_SHAPE;
+    } else {
+        if (!xyz || !viewdirs) return PNR_E_NULL;
+        src.xyz = xyz; src.dirs = viewdirs; src.K = 1;
+    }
+    if (n_points < 0 || points_per_obj <= 0 || n_points != points_per_obj * views->n_objs) return PNR_E_SHAPE;
+    if (!workspace && n_points > 0) return PNR_E_NULL;
+    return point_dispatch(params, mlp, views, src, n_points, points_per_obj, out, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+struct RenderWs { uint64_t zc, zf, rgbs, w, rgb, depth, point, total; };
+
+static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t n) {
+    RenderWs r;
+    uint64_t Kc = prm->n_coarse, Kt = (uint64_t)prm->n_coarse + prm->n_fine, off = 0;
+    r.zc = off; off += align256(n * Kc * 4);
+    r.zf = off; off += align256(n * Kt * 4);
+    r.rgbs = off; off += align256(n * Kt * 16);
+    r.w = off; off += align256(n * Kt * 4);
+    r.rgb = off; off += align256(n * 12);
+    r.depth = off; off += align256(n * 4);
+    r.point = off; off += align256(point_workspace_bytes(prm, mlp, vw));
+    r.total = off + 256;
+    return r;
+}
+
+extern "C" uint64_t pnr_workspace_bytes(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                        int64_t n_rays) {
+    if (!params || !mlp || !views || n_rays < 0) return 0;
+    return carve(params, mlp, views, n_rays).total;
+}
+
+extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
+                              const pnr_views* views, const float* rays, int64_t n_rays, int64_t rays_per_obj,
+                              const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
+                              const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream) {
+    int32_t rc = check_model(params, coarse, views);
+    if (rc) return rc;
+    if (fine && (rc = check_model(params, fine, views))) return rc;
+    if (!rays || !outputs) return PNR_E_NULL;
+    if (params->n_coarse < 1 || params->n_fine < 0 || params->n_fine_depth < 0 ||
+        params->n_fine_depth > params->n_fine) return PNR_E_SHAPE;
+    if (n_rays < 0 || rays_per_obj <= 0 || n_rays != rays_per_obj * views->n_objs) return PNR_E_SHAPE;
+    if (n_rays == 0) return PNR_OK;
+    if (!workspace) return PNR_E_NULL;
+    RenderWs cw = carve(params, coarse, views, n_rays);
+    if (workspace_bytes < cw.total) return PNR_E_WORKSPACE;
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipStream_t s = (hipStream_t)stream;
+    const int Kc = params->n_coarse, Kf = params->n_fine, Kfd = params->n_fine_depth, Kt = Kc + Kf;
+    float* zc = outputs->z_coarse ? outputs->z_coarse : (float*)(base + cw.zc);
+    float* zf = outputs->z_fine ? outputs->z_fine : (float*)(base + cw.zf);
+    float* rgbs = (float*)(base + cw.rgbs);
+    float* w_c = outputs->coarse_weights ? outputs->coarse_weights : (float*)(base + cw.w);
+    float* rgb_c = outputs->coarse_rgb ? outputs->coarse_rgb : (float*)(base + cw.rgb);
+    float* dep_c = outputs->coarse_depth ? outputs->coarse_depth : (float*)(base + cw.depth);
+    void* pws = base + cw.point;
+    uint64_t pws_bytes = workspace_bytes - (uint64_t)((char*)pws - (char*)workspace);
+    const pnr_noise nz = noise ? *noise : pnr_noise{nullptr, nullptr, nullptr, nullptr};
+
+    // coarse pass (nerf.py:273-282)
+    if ((rc = pnr_sample_coarse(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, ray_index_base, zc, stream))) return rc;
+    PointSrc src{rays, zc, Kc, nullptr, nullptr};
+    if ((rc = point_dispatch(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s))) return rc;
+    if ((rc = pnr_composite(rays, zc, rgbs, n_rays, Kc, params->white_bkgd, w_c, rgb_c, dep_c, stream))) return rc;
+    if (Kf == 0) return PNR_OK;
+
+    // fine pass (nerf.py:284-301); mlp_fine=None falls back to the coarse MLP (backup2:258)
+    if (!outputs->fine_rgb || !outputs->fine_depth) return PNR_E_NULL;
+    if ((rc = pnr_sample_fine(rays, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
+                              nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream))) return rc;
+    PointSrc srcf{rays, zf, Kt, nullptr, nullptr};
+    if ((rc = point_dispatch(params, fine ? fine : coarse, views, srcf, n_rays * Kt, rays_per_obj * Kt, rgbs, pws,
+                             pws_bytes, s))) return rc;
+    return pnr_composite(rays, zf, rgbs, n_rays, Kt, params->white_bkgd, outputs->fine_weights, outputs->fine_rgb,
+                         outputs->fine_depth, stream);
+}
+
+// ---- hipEvent helpers for ctypes callers (bench.py times kernels on the stream they run on)
+extern "C" int32_t pnr_event_create(void** ev) {
+    if (!ev) return PNR_E_NULL;
+    hipEvent_t e;
+    PNR_HIP_CHECK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return PNR_OK;
+}
+extern "C" int32_t pnr_event_record(void* ev, void* stream) {
+    if (!ev) return PNR_E_NULL;
+    PNR_HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return PNR_OK;
+}
+extern "C" int32_t pnr_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!start || !stop || !ms) return PNR_E_NULL;
+    PNR_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    PNR_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PNR_OK;
+}
+extern "C" int32_t pnr_event_destroy(void* ev) {
+    if (!ev) return PNR_E_NULL;
+    PNR_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+    return PNR_OK;
+}

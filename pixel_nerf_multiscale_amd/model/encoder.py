@@ -1,0 +1,114 @@
+"""
+SpatialEncoder: holder of the pixel-aligned latent map(s) the render kernels sample, plus a plain
+torch.nn ResNet trunk (torchvision key names, so upstream checkpoints load) that produces them once per
+object via PyTorch-ROCm/MIOpen.  Reference: src/model/encoder.py.  The per-point lookup `index()` of the
+reference (encoder.py:138-205) happens inside the HIP point kernel; see csrc/pnr_common.h bilinear_taps.
+"""
+import torch
+from torch import nn
+
+from ..util import as_conf
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + idt)
+
+
+class _ResNetTrunk(nn.Module):
+    """ResNet-18/34 feature trunk with torchvision's module names (conv1, bn1, layer1..4, fc)."""
+
+    def __init__(self, depths):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        chans, cin = (64, 128, 256, 512), 64
+        for i, (d, c) in enumerate(zip(depths, chans)):
+            blocks = [_BasicBlock(cin if j == 0 else c, c, (2 if i > 0 and j == 0 else 1)) for j in range(d)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+            cin = c
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, 1000)
+
+
+_DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+class SpatialEncoder(nn.Module):
+    def __init__(self, backbone="resnet34", pretrained=True, num_layers=4, index_interp="bilinear",
+                 index_padding="border", upsample_interp="bilinear", feature_scale=1.0, use_first_pool=True,
+                 norm_type="batch", use_multi_scale=False):
+        super().__init__()
+        if backbone not in _DEPTHS:
+            raise NotImplementedError(f"Backbone {backbone} not supported")
+        if index_interp != "bilinear" or index_padding != "border":
+            raise NotImplementedError("the render kernels implement bilinear/border lookup only")
+        self.use_multi_scale, self.num_layers = use_multi_scale, num_layers
+        self.feature_scale, self.use_first_pool = feature_scale, use_first_pool
+        self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
+        self.align_corners = True
+        # pretrained ImageNet weights cannot be downloaded here; load a checkpoint's state-dict instead
+        self.model = _ResNetTrunk(_DEPTHS[backbone])
+        sizes = [64, 64, 128, 256, 512][:num_layers]
+        stem = [self.model.conv1, self.model.bn1, self.model.relu] + ([self.model.maxpool] if use_first_pool else [])
+        self.layers = nn.ModuleList([nn.Sequential(*stem)] +
+                                    [getattr(self.model, f"layer{i}") for i in range(1, num_layers)])
+        self.latent_size = sizes if use_multi_scale else sizes[-1]
+        self.latent = None      # plain attributes, like the reference (encoder.py:106-107)
+        self.latents = []
+
+    def forward(self, x):
+        x = x * self.feature_scale
+        feats = []
+        for layer in self.layers:
+            x = layer(x)
+            feats.append(x)
+        self.set_latents(feats if self.use_multi_scale else [feats[-1]])
+        return self.latents if self.use_multi_scale else self.latent
+
+    def set_latents(self, maps):
+        """Install latent map(s) (list of (SB*NS, C, H, W)) — what forward() leaves on the module."""
+        maps = [m.detach().float().contiguous() for m in maps]
+        self.latents = maps if self.use_multi_scale else []
+        self.latent = maps[-1]
+        self._level_maps = maps
+
+    def level_maps(self):
+        if self.latent is None:
+            raise RuntimeError("encoder has no latent yet: call PixelNeRFNet.encode() first")
+        return self.latents if self.use_multi_scale else [self.latent]
+
+    def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
+        raise RuntimeError(
+            "SpatialEncoder.index is fused into the HIP point kernel (pnr_point_mlp); call "
+            "PixelNeRFNet.forward / NeRFRenderer instead")
+
+    @classmethod
+    def from_conf(cls, conf, **kwargs):
+        conf = as_conf(conf)
+        return cls(backbone=conf.get("backbone", "resnet34"), pretrained=conf.get("pretrained", True),
+                   num_layers=conf.get("num_layers", 4), index_interp=conf.get("index_interp", "bilinear"),
+                   index_padding=conf.get("index_padding", "border"),
+                   upsample_interp=conf.get("upsample_interp", "bilinear"),
+                   feature_scale=conf.get("feature_scale", 1.0), use_first_pool=conf.get("use_first_pool", True),
+                   norm_type=conf.get("norm_type", "batch"), use_multi_scale=conf.get("use_multi_scale", False),
+                   **kwargs)
+
+
+ImageEncoder = SpatialEncoder

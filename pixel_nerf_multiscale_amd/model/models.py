@@ -1,0 +1,274 @@
+"""
+PixelNeRFNet with the reference's Python surface (reference src/model/models.py.backup2, the working
+variant — SURVEY.md D3): same constructor / encode / forward / load_weights / save_weights, same
+state-dict keys.  forward() and the renderer's fused path evaluate the network in libpnr_hip.so.
+"""
+import ctypes as C
+import os
+import os.path as osp
+import warnings
+
+import torch
+
+from .. import _native as N
+from ..util import as_conf
+from .code import PositionalEncoding
+from .encoder import ImageEncoder, SpatialEncoder
+from .resnetfc import ResnetFC
+
+
+def make_encoder(conf, **kwargs):
+    conf = as_conf(conf)
+    enc_type = conf.get_string("type", "spatial")
+    if enc_type in ("spatial", "global"):
+        return SpatialEncoder.from_conf(conf, **kwargs)
+    raise NotImplementedError("Unsupported encoder type")
+
+
+def make_mlp(conf, d_in, d_latent=0, allow_empty=False, **kwargs):
+    conf = as_conf(conf)
+    mlp_type = conf.get_string("type", "mlp")
+    if mlp_type == "resnet":
+        return ResnetFC.from_conf(conf, d_in, d_latent=d_latent, **kwargs)
+    if mlp_type == "empty" and allow_empty:
+        return None
+    raise NotImplementedError("Unsupported MLP type " + mlp_type)   # 'mlp' (ImplicitNet) is unreachable upstream (D7)
+
+
+class PixelNeRFNet(torch.nn.Module):
+    def __init__(self, conf, stop_encoder_grad=False):
+        super().__init__()
+        conf = as_conf(conf)
+        self.encoder = make_encoder(conf["encoder"])
+        self.use_encoder = conf.get_bool("use_encoder", True)
+        self.use_xyz = conf.get_bool("use_xyz", False)
+        self.normalize_z = conf.get_bool("normalize_z", True)
+        self.stop_encoder_grad = stop_encoder_grad
+        self.use_code = conf.get_bool("use_code", False)
+        self.use_code_viewdirs = conf.get_bool("use_code_viewdirs", True)
+        self.use_viewdirs = conf.get_bool("use_viewdirs", False)
+        self.use_global_encoder = conf.get_bool("use_global_encoder", False)
+        if not (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code and self.use_viewdirs) \
+                or self.use_global_encoder:
+            raise NotImplementedError(
+                "the HIP path implements the shipped configuration family: use_encoder, use_xyz, normalize_z, "
+                "use_code, use_viewdirs all true and no global encoder (conf/default.conf)")
+
+        lat = self.encoder.latent_size
+        self.latent_size = int(sum(lat)) if isinstance(lat, (list, tuple)) else int(lat)
+        d_latent = self.latent_size
+        d_in = 6 if self.use_code_viewdirs else 3
+        self.code = PositionalEncoding.from_conf(conf["code"], d_in=d_in)
+        d_in = self.code.d_out + (0 if self.use_code_viewdirs else 3)
+        d_out = 4
+        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_latent, d_out=d_out)
+        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_latent, d_out=d_out, allow_empty=True)
+        # world -> camera, bottom row omitted; set by encode()
+        self.register_buffer("poses", torch.empty(1, 3, 4), persistent=False)
+        self.register_buffer("image_shape", torch.empty(2), persistent=False)
+        self.register_buffer("focal", torch.empty(1, 2), persistent=False)
+        self.register_buffer("c", torch.empty(1, 2), persistent=False)
+        self.d_in, self.d_out, self.d_latent = d_in, d_out, d_latent
+        self.num_objs = 0
+        self.num_views_per_obj = 1
+        # arithmetic of the fc layers: "auto" = bf16 MFMA kernel when the shape allows, else the fp32 HIP path
+        self.precision = conf.get_string("precision", os.environ.get("PNR_PRECISION", "auto"))
+        self._pack_cache = {}
+        self._ws = None
+
+    # ------------------------------------------------------------------ camera setup (backup2:98-150)
+    def encode(self, images, poses, focal, z_bounds=None, c=None):
+        self.num_objs = images.size(0)
+        if images.dim() == 5:
+            assert poses.dim() == 4 and poses.size(1) == images.size(1)
+            self.num_views_per_obj = images.size(1)
+            images = images.reshape(-1, *images.shape[2:])
+            poses = poses.reshape(-1, 4, 4)
+        else:
+            self.num_views_per_obj = 1
+        self.encoder(images)
+        self.set_cameras(poses, focal, c, images.shape[-1], images.shape[-2])
+
+    def set_cameras(self, poses, focal, c, width, height):
+        """The camera half of encode(): w2c = [R^T | -R^T t], image_shape = (W, H), focal -> (.,2) with fy
+        negated, c defaulting to the image centre.  poses: (SB*NS, 4, 4) camera-to-world."""
+        dev = self.poses.device
+        poses = poses.to(dev).float().reshape(-1, 4, 4)
+        rot = poses[:, :3, :3].transpose(1, 2)
+        trans = -torch.bmm(rot, poses[:, :3, 3:])
+        self.poses = torch.cat((rot, trans), dim=-1).contiguous()
+        self.image_shape = torch.tensor([float(width), float(height)], device=dev)
+        focal = torch.as_tensor(focal, dtype=torch.float32, device=dev)
+        if focal.dim() == 0:
+            focal = focal[None, None].repeat(1, 2)
+        elif focal.dim() == 1:
+            focal = focal.unsqueeze(-1).repeat(1, 2)
+        else:
+            focal = focal.clone()
+        focal = focal.float().clone()
+        focal[..., 1] *= -1.0
+        self.focal = focal.contiguous()
+        if c is None:
+            c = (self.image_shape * 0.5).unsqueeze(0)
+        else:
+            c = torch.as_tensor(c, dtype=torch.float32, device=dev)
+            if c.dim() == 0:
+                c = c[None, None].repeat(1, 2)
+            elif c.dim() == 1:
+                c = c.unsqueeze(-1).repeat(1, 2)
+        self.c = c.float().contiguous()
+
+    # ------------------------------------------------------------------ native descriptors
+    def resolved_precision(self, mlp=None):
+        p = self.precision
+        mlp = mlp if mlp is not None else self.mlp_coarse
+        if p == "auto":
+            return "bf16" if mfma_supported(mlp, self) else "fp32"
+        if p not in N.PRECISIONS:
+            raise ValueError(f"unknown precision {p!r}")
+        return p
+
+    def params_struct(self, renderer=None, precision=None):
+        prm = N.pnr_params()
+        if renderer is not None:
+            prm.n_coarse, prm.n_fine, prm.n_fine_depth = int(renderer.n_coarse), int(renderer.n_fine), int(renderer.n_fine_depth)
+            prm.white_bkgd, prm.lindisp = int(bool(renderer.white_bkgd)), int(bool(renderer.lindisp))
+            prm.depth_std = float(renderer.depth_std)
+        else:
+            prm.n_coarse = 1
+        prm.use_code_viewdirs = int(self.use_code_viewdirs)
+        prm.num_freqs = int(self.code.num_freqs)
+        prm.freq_factor = float(self.code.freq_factor)
+        prm.precision = N.PRECISIONS[precision or self.resolved_precision()]
+        return prm
+
+    def mlp_struct(self, mlp, precision):
+        """pnr_mlp over the module's parameter storage (+ the packed MFMA stream, cached until a
+        parameter changes).  Returns (struct, keepalive)."""
+        m = N.pnr_mlp()
+        m.d_in, m.d_latent, m.d_hidden, m.d_out = mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out
+        m.n_blocks, m.combine_layer, m.combine_type = mlp.n_blocks, mlp.combine_layer, N.COMBINE[mlp.combine_type]
+        keep = []
+
+        def P(t):
+            t = N.f32c(t.detach())
+            keep.append(t)
+            return N.ptr(t)
+
+        m.lin_in_w, m.lin_in_b = P(mlp.lin_in.weight), P(mlp.lin_in.bias)
+        m.lin_out_w, m.lin_out_b = P(mlp.lin_out.weight), P(mlp.lin_out.bias)
+        for b, blk in enumerate(mlp.blocks):
+            m.fc0_w[b], m.fc0_b[b] = P(blk.fc_0.weight), P(blk.fc_0.bias)
+            m.fc1_w[b], m.fc1_b[b] = P(blk.fc_1.weight), P(blk.fc_1.bias)
+        if mlp.d_latent:
+            for b, lz in enumerate(mlp.lin_z):
+                m.lin_z_w[b], m.lin_z_b[b] = P(lz.weight), P(lz.bias)
+        if precision != "fp32":
+            key = ("mlp", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()))
+            packed = self._pack_cache.get(key)
+            if packed is None:
+                self._pack_cache = {k: v for k, v in self._pack_cache.items() if not (k[0] == "mlp" and k[1] == id(mlp))}
+                nbytes = N.lib.pnr_packed_mlp_bytes(C.byref(m))
+                if nbytes == 0:
+                    raise ValueError("this MLP shape is not supported by the MFMA kernel; use precision='fp32'")
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=keep[0].device)
+                N.check(N.lib.pnr_pack_mlp(C.byref(m), N.PRECISIONS[precision], packed.data_ptr(), nbytes,
+                                           N.current_stream(packed.device)), "pnr_pack_mlp")
+                self._pack_cache[key] = packed
+            m.packed, m.packed_bytes, m.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
+            keep.append(packed)
+        return m, keep
+
+    def views_struct(self, precision):
+        maps = self.encoder.level_maps()
+        dev = maps[0].device
+        v = N.pnr_views()
+        keep = []
+        nv = maps[0].shape[0]
+        v.n_views = int(self.num_views_per_obj)
+        v.n_objs = nv // v.n_views
+        for name in ("poses", "focal", "c"):
+            t = N.f32c(getattr(self, name), dev)
+            keep.append(t)
+            setattr(v, {"poses": "w2c"}.get(name, name), N.ptr(t))
+        if self.poses.shape[0] != nv:
+            raise ValueError(f"{self.poses.shape[0]} cameras but {nv} latent maps")
+        v.n_focal, v.n_c = self.focal.shape[0], self.c.shape[0]
+        v.n_levels = len(maps)
+        for i, mp in enumerate(maps):
+            mp = N.f32c(mp)
+            keep.append(mp)
+            v.latent[i] = N.ptr(mp)
+            v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+        if precision != "fp32":
+            key = ("lat", precision, tuple((mp.data_ptr(), mp._version, tuple(mp.shape)) for mp in maps))
+            packed = self._pack_cache.get(key)
+            if packed is None:
+                self._pack_cache = {k: t for k, t in self._pack_cache.items() if k[0] != "lat"}
+                nbytes = N.lib.pnr_packed_latent_bytes(C.byref(v))
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                N.check(N.lib.pnr_pack_latents(C.byref(v), N.PRECISIONS[precision], packed.data_ptr(), nbytes,
+                                               N.current_stream(dev)), "pnr_pack_latents")
+                self._pack_cache[key] = packed
+            v.latent_packed, v.latent_packed_bytes, v.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
+            keep.append(packed)
+        return v, keep
+
+    def workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ per-point evaluation (backup2:155-282)
+    def forward(self, xyz, coarse=True, viewdirs=None, far=False):
+        """xyz (SB, B, 3) world points [, viewdirs (SB, B, 3)] -> (SB, B, 4) = sigmoid(rgb), relu(sigma)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and xyz.requires_grad:
+            raise NotImplementedError("backward through the HIP render path is not implemented (SURVEY N4)")
+        assert viewdirs is not None, "use_viewdirs is on: viewdirs required"
+        SB, B, _ = xyz.shape
+        mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        prec = self.resolved_precision(mlp)
+        dev = xyz.device
+        xyz_c, vd_c = N.f32c(xyz), N.f32c(viewdirs.reshape(SB, B, 3))
+        prm = self.params_struct(None, prec)
+        m, k1 = self.mlp_struct(mlp, prec)
+        v, k2 = self.views_struct(prec)
+        if v.n_objs != SB:
+            raise ValueError(f"xyz has {SB} objects but encode() saw {v.n_objs}")
+        out = torch.empty(SB, B, 4, device=dev, dtype=torch.float32)
+        nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(m), C.byref(v), 0)
+        ws = self.workspace(nbytes, dev)
+        N.check(N.lib.pnr_point_mlp(C.byref(prm), C.byref(m), C.byref(v), None, None, 0, N.ptr(xyz_c), N.ptr(vd_c),
+                                    SB * B, B, N.ptr(out), ws.data_ptr(), ws.numel(), N.current_stream(dev)),
+                "pnr_point_mlp")
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (backup2:284-332)
+    def load_weights(self, args, opt_init=False, strict=True, device=None):
+        if opt_init and not args.resume:
+            return
+        ckpt_name = "pixel_nerf_init" if opt_init or not args.resume else "pixel_nerf_latest"
+        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
+        device = self.poses.device if device is None else device
+        if os.path.exists(model_path):
+            print("Load", model_path)
+            self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True), strict=strict)
+        elif not opt_init:
+            warnings.warn(f"WARNING: {model_path} does not exist, not loaded!! Model will be re-initialized.")
+        return self
+
+    def save_weights(self, args, opt_init=False):
+        from shutil import copyfile
+        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
+        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
+        if osp.exists(ckpt_path):
+            copyfile(ckpt_path, osp.join(args.checkpoints_path, args.name, backup_name))
+        torch.save(self.state_dict(), ckpt_path)
+        return self
+
+
+def mfma_supported(mlp, net):
+    """Shapes the fused MFMA kernel is specialised for (csrc/point_mfma.hip)."""
+    return (mlp.d_hidden == 512 and mlp.d_out == 4 and mlp.d_latent % 256 == 0 and mlp.d_latent > 0
+            and mlp.d_in <= 80 and 1 <= mlp.n_blocks <= 8)

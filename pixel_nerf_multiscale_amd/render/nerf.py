@@ -1,0 +1,237 @@
+"""
+NeRFRenderer with the reference's Python surface (reference src/render/nerf.py), executing on
+libpnr_hip.so:
+  * model is this package's PixelNeRFNet  -> ONE native call (pnr_render): sampling, point network,
+    compositing, fine resampling all on the GPU, nothing materialised per point in PyTorch;
+  * any other callable `model(xyz, coarse=, viewdirs=)` (the reference's protocol, nerf.py:188,212-216)
+    -> the HIP sampling / compositing stages around chunked calls of that model.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _native as N
+from ..util import AttrDict, as_conf, seed_from_torch
+
+
+class _RenderWrapper(torch.nn.Module):
+    """(rays, want_weights) -> (rgb, depth) or nested dict, always with the bound net (nerf.py:15-42)."""
+
+    def __init__(self, net, renderer, simple_output):
+        super().__init__()
+        self.net, self.renderer, self.simple_output = net, renderer, simple_output
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
+        outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output)
+        if self.simple_output:
+            lvl = outputs.fine if self.renderer.using_fine else outputs.coarse
+            return lvl.rgb, lvl.depth
+        return outputs.toDict()
+
+
+class NeRFRenderer(torch.nn.Module):
+    def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01,
+                 eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None):
+        super().__init__()
+        self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
+        self.noise_std, self.depth_std = noise_std, depth_std
+        self.eval_batch_size = eval_batch_size
+        self.white_bkgd, self.lindisp = white_bkgd, lindisp
+        if lindisp:
+            print("Using linear displacement rays")
+        self.using_fine = n_fine > 0
+        self.sched = sched if sched is not None and len(sched) > 0 else None
+        self.register_buffer("iter_idx", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.register_buffer("last_sched", torch.tensor(0, dtype=torch.long), persistent=True)
+        # Random draws: None -> in-kernel counter-based generator seeded from torch's global generator
+        # (so torch.manual_seed governs it, like the reference's torch.rand calls); or a dict with any of
+        # noise_c (N,Kc), u (N,Kf-Kfd), r (N,Kf-Kfd), g (N,Kfd) to inject explicit draws (parity tests).
+        self.fixed_noise = None
+        self.ray_index_base = 0      # global index of rays[0] when a frame is sharded over ranks
+        self.last_seed = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ stage wrappers (reference method names)
+    def _noise_ptrs(self, dev):
+        nz, keep = N.pnr_noise(), []
+        if self.fixed_noise:
+            for k in ("noise_c", "u", "r", "g"):
+                t = self.fixed_noise.get(k)
+                if t is not None:
+                    t = N.f32c(t, dev)
+                    keep.append(t)
+                    setattr(nz, k, N.ptr(t))
+        return nz, keep
+
+    def _seed(self):
+        self.last_seed = seed_from_torch()
+        return self.last_seed
+
+    def sample_coarse(self, rays, seed=None):
+        """rays (B,8) -> z (B,Kc): stratified, jittered in eval too (nerf.py:98-118)."""
+        rays = N.f32c(rays)
+        z = torch.empty(rays.shape[0], self.n_coarse, device=rays.device)
+        nz, keep = self._noise_ptrs(rays.device)
+        N.check(N.lib.pnr_sample_coarse(N.ptr(rays), rays.shape[0], self.n_coarse, int(self.lindisp), nz.noise_c,
+                                        self._seed() if seed is None else seed, self.ray_index_base, N.ptr(z),
+                                        N.current_stream(rays.device)), "pnr_sample_coarse")
+        return z
+
+    def sample_fine_sorted(self, rays, z_coarse, weights, depth, seed=None):
+        """sample_fine + sample_fine_depth + cat + sort (nerf.py:120-161,285-295) -> (B, Kc+Kf) ascending."""
+        rays = N.f32c(rays)
+        B = rays.shape[0]
+        z = torch.empty(B, self.n_coarse + self.n_fine, device=rays.device)
+        nz, keep = self._noise_ptrs(rays.device)
+        w = N.f32c(weights.detach())
+        d = N.f32c(depth.detach())
+        zc = N.f32c(z_coarse)
+        N.check(N.lib.pnr_sample_fine(N.ptr(rays), N.ptr(zc), N.ptr(w), N.ptr(d), B, self.n_coarse, self.n_fine,
+                                      self.n_fine_depth, float(self.depth_std), int(self.lindisp), nz.u, nz.r, nz.g,
+                                      self.last_seed if seed is None else seed, self.ray_index_base, N.ptr(z),
+                                      N.current_stream(rays.device)), "pnr_sample_fine")
+        return z
+
+    def composite(self, model, rays, z_samp, coarse=True, sb=0):
+        """Generic-model compositing (nerf.py:163-249): chunked model calls + the HIP compositing stage."""
+        rays, z_samp = N.f32c(rays), N.f32c(z_samp)
+        B, K = z_samp.shape
+        points = (rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6])
+        use_viewdirs = hasattr(model, "use_viewdirs") and model.use_viewdirs
+        if sb > 0:
+            points = points.reshape(sb, -1, 3)
+            bs, dim = (self.eval_batch_size - 1) // sb + 1, 1
+        else:
+            points = points.reshape(-1, 3)
+            bs, dim = self.eval_batch_size, 0
+        if use_viewdirs:
+            dirs = rays[:, None, 3:6].expand(-1, K, -1)
+            dirs = dirs.reshape(sb, -1, 3) if sb > 0 else dirs.reshape(-1, 3)
+            vals = [model(p, coarse=coarse, viewdirs=d)
+                    for p, d in zip(torch.split(points, bs, dim=dim), torch.split(dirs, bs, dim=dim))]
+        else:
+            vals = [model(p, coarse=coarse) for p in torch.split(points, bs, dim=dim)]
+        out = N.f32c(torch.cat(vals, dim=dim).reshape(B, K, -1)[..., :4])
+        return self._composite_native(rays, z_samp, out)
+
+    def _composite_native(self, rays, z_samp, out):
+        B, K = z_samp.shape
+        dev = rays.device
+        weights = torch.empty(B, K, device=dev)
+        rgb = torch.empty(B, 3, device=dev)
+        depth = torch.empty(B, device=dev)
+        N.check(N.lib.pnr_composite(N.ptr(rays), N.ptr(z_samp), N.ptr(out), B, K, int(bool(self.white_bkgd)),
+                                    N.ptr(weights), N.ptr(rgb), N.ptr(depth), N.current_stream(dev)), "pnr_composite")
+        return weights, rgb, depth
+
+    # ------------------------------------------------------------------ forward (nerf.py:251-303)
+    def forward(self, model, rays, want_weights=False):
+        if self.sched is not None and self.last_sched.item() > 0:
+            self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+            self.n_fine = self.sched[2][self.last_sched.item() - 1]
+        assert len(rays.shape) == 3
+        if not rays.is_cuda:
+            raise RuntimeError("NeRFRenderer runs on the HIP device only: move rays (and the model) to cuda")
+        if self.training and self.noise_std > 0.0:
+            raise NotImplementedError("sigma noise (training only, nerf.py:225-226) is not implemented")
+        from ..model.models import PixelNeRFNet
+        if isinstance(model, PixelNeRFNet):
+            return self._forward_fused(model, rays, want_weights)
+        return self._forward_generic(model, rays, want_weights)
+
+    def _forward_fused(self, net, rays, want_weights):
+        SB, B, _ = rays.shape
+        dev = rays.device
+        rays_f = N.f32c(rays).reshape(-1, 8)
+        n = SB * B
+        Kc, Kf = int(self.n_coarse), int(self.n_fine) if self.using_fine else 0
+        prec_c = net.resolved_precision(net.mlp_coarse)
+        prm = net.params_struct(self, prec_c)
+        prm.n_fine = Kf
+        prm.n_fine_depth = int(self.n_fine_depth) if Kf > 0 else 0
+        mc, k1 = net.mlp_struct(net.mlp_coarse, prec_c)
+        fine_mod = net.mlp_fine if (Kf > 0 and net.mlp_fine is not None) else None
+        mf, k2 = net.mlp_struct(fine_mod, prec_c) if fine_mod is not None else (None, [])
+        v, k3 = net.views_struct(prec_c)
+        if v.n_objs != SB:
+            raise ValueError(f"rays has {SB} objects but encode() saw {v.n_objs}")
+        o = N.pnr_outputs()
+        res = AttrDict(coarse=AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev)))
+        o.coarse_rgb, o.coarse_depth = N.ptr(res.coarse.rgb), N.ptr(res.coarse.depth)
+        if want_weights:
+            res.coarse.weights = torch.empty(SB, B, Kc, device=dev)
+            o.coarse_weights = N.ptr(res.coarse.weights)
+        if Kf > 0:
+            res.fine = AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev))
+            o.fine_rgb, o.fine_depth = N.ptr(res.fine.rgb), N.ptr(res.fine.depth)
+            if want_weights:
+                res.fine.weights = torch.empty(SB, B, Kc + Kf, device=dev)
+                o.fine_weights = N.ptr(res.fine.weights)
+        if getattr(self, "keep_samples", False):
+            res.coarse.z = torch.empty(SB, B, Kc, device=dev)
+            o.z_coarse = N.ptr(res.coarse.z)
+            if Kf > 0:
+                res.fine.z = torch.empty(SB, B, Kc + Kf, device=dev)
+                o.z_fine = N.ptr(res.fine.z)
+        nz, k4 = self._noise_ptrs(dev)
+        nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mc), C.byref(v), n)
+        ws = net.workspace(nbytes, dev)
+        N.check(N.lib.pnr_render(C.byref(prm), C.byref(mc), C.byref(mf) if mf is not None else None, C.byref(v),
+                                 N.ptr(rays_f), n, B, C.byref(nz), self._seed(), int(self.ray_index_base), C.byref(o),
+                                 ws.data_ptr(), ws.numel(), N.current_stream(dev)), "pnr_render")
+        return res
+
+    def _forward_generic(self, model, rays, want_weights):
+        SB = rays.shape[0]
+        r = N.f32c(rays).reshape(-1, 8)
+        z_coarse = self.sample_coarse(r)
+        wc, rgbc, dc = self.composite(model, r, z_coarse, coarse=True, sb=SB)
+        res = AttrDict(coarse=self._format_outputs((wc, rgbc, dc), SB, want_weights))
+        if self.using_fine:
+            z_all = self.sample_fine_sorted(r, z_coarse, wc, dc)
+            res.fine = self._format_outputs(self.composite(model, r, z_all, coarse=False, sb=SB), SB, want_weights)
+        return res
+
+    def _format_outputs(self, rendered, superbatch_size, want_weights=False):
+        weights, rgb, depth = rendered
+        if superbatch_size > 0:
+            rgb = rgb.reshape(superbatch_size, -1, 3)
+            depth = depth.reshape(superbatch_size, -1)
+            weights = weights.reshape(superbatch_size, -1, weights.shape[-1])
+        ret = AttrDict(rgb=rgb, depth=depth)
+        if want_weights:
+            ret.weights = weights
+        return ret
+
+    # ------------------------------------------------------------------ schedule / construction (nerf.py:318-371)
+    def sched_step(self, steps=1):
+        if self.sched is None:
+            return
+        self.iter_idx += steps
+        while self.last_sched.item() < len(self.sched[0]) and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]:
+            self.n_coarse = self.sched[1][self.last_sched.item()]
+            self.n_fine = self.sched[2][self.last_sched.item()]
+            print("INFO: NeRF sampling resolution changed on schedule ==> c", self.n_coarse, "f", self.n_fine)
+            self.last_sched += 1
+
+    @classmethod
+    def from_conf(cls, conf, white_bkgd=False, lindisp=False, eval_batch_size=100000):
+        conf = as_conf(conf)
+        return cls(conf.get_int("n_coarse", 128), conf.get_int("n_fine", 0),
+                   n_fine_depth=conf.get_int("n_fine_depth", 0), noise_std=conf.get_float("noise_std", 0.0),
+                   depth_std=conf.get_float("depth_std", 0.01), white_bkgd=conf.get_float("white_bkgd", white_bkgd),
+                   lindisp=lindisp, eval_batch_size=conf.get_int("eval_batch_size", eval_batch_size),
+                   sched=conf.get_list("sched", None))
+
+    def bind_parallel(self, net, gpus=None, simple_output=False):
+        """Callable (rays, want_weights) bound to `net` (nerf.py:354-371).  The reference wraps it in
+        nn.DataParallel when several gpus are given; here multi-GPU is one process per GPU
+        (pixel_nerf_multiscale_amd.parallel.ShardedRenderer over RCCL), so `gpus` with more than one id is
+        rejected rather than silently running on one device."""
+        if gpus is not None and len(gpus) > 1:
+            raise NotImplementedError(
+                "single-process multi-GPU (nn.DataParallel) is replaced by one process per GPU: launch with "
+                "torch.distributed.run and wrap with pixel_nerf_multiscale_amd.parallel.ShardedRenderer")
+        return _RenderWrapper(net, self, simple_output=simple_output)

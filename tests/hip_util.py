@@ -1,0 +1,57 @@
+"""Builds this package's PixelNeRFNet / NeRFRenderer from a fixture spec (same synthetic weights,
+latents and cameras the reference was run with)."""
+import torch
+
+import golden_util as gu
+from oracle_util import noise_from_fixture
+
+
+def model_conf(spec, precision="fp32"):
+    mlp = dict(type="resnet", n_blocks=spec["n_blocks"], d_hidden=spec["d_hidden"],
+               combine_layer=spec["combine_layer"], combine_type=spec["combine_type"])
+    return dict(
+        use_encoder=True, use_global_encoder=False, use_xyz=True, normalize_z=True, use_code=True,
+        code=dict(num_freqs=6, freq_factor=1.5, include_input=True), use_viewdirs=True,
+        use_code_viewdirs=spec["use_code_viewdirs"], mlp_coarse=dict(mlp),
+        mlp_fine=dict(mlp) if spec["fine_mlp"] else dict(type="empty"),
+        encoder=dict(backbone="resnet34", pretrained=False, num_layers=4, use_multi_scale=len(spec["lat"]) > 1),
+        precision=precision)
+
+
+def build_net(spec, poses, device="cuda", precision="fp32"):
+    from pixel_nerf_multiscale_amd import PixelNeRFNet
+    from pixel_nerf_multiscale_amd.model import ResnetFC
+    net = PixelNeRFNet(model_conf(spec, precision))
+    L = gu.d_latent_of(spec)
+    if L != net.d_latent:      # synthetic latent width (tiny cases)
+        mk = lambda: ResnetFC(net.d_in, d_out=4, n_blocks=spec["n_blocks"], d_latent=L, d_hidden=spec["d_hidden"],
+                              combine_layer=spec["combine_layer"], combine_type=spec["combine_type"])
+        net.mlp_coarse = mk()
+        if net.mlp_fine is not None:
+            net.mlp_fine = mk()
+        net.latent_size = net.d_latent = L
+    for which, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)):
+        if mlp is not None:
+            mlp.load_state_dict({k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, which).items()}, strict=True)
+    net = net.to(device).eval()
+    net.encoder.set_latents([torch.from_numpy(x).to(device) for x in gu.make_latents(spec)])
+    W, H = spec["image"]
+    net.num_objs, net.num_views_per_obj = spec["SB"], spec["NS"]
+    net.set_cameras(torch.from_numpy(poses).reshape(-1, 4, 4), torch.tensor(spec["focal"]), None, W, H)
+    return net
+
+
+def build_renderer(spec, device="cuda"):
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    r = NeRFRenderer(n_coarse=spec["Kc"], n_fine=spec["Kf"], n_fine_depth=spec["Kfd"], depth_std=spec["depth_std"],
+                     white_bkgd=spec["white_bkgd"], lindisp=spec["lindisp"])
+    return r.to(device).eval()
+
+
+def setup(name, device="cuda", precision="fp32"):
+    fx = gu.load_fixture(name)
+    spec = fx["spec"]
+    net = build_net(spec, fx["poses"], device, precision)
+    rend = build_renderer(spec, device)
+    rend.fixed_noise = {k: v.to(device) for k, v in noise_from_fixture(fx).items()}
+    return fx, spec, net, rend

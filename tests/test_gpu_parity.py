@@ -1,0 +1,179 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden fixtures produced by the
+reference and against the oracle restatement, on the same inputs and the same recorded noise.
+Tolerances: fp32 path |d rgb|, |d w| <= 1e-4, |d depth| <= 1e-4*(far-near)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import pixelnerf_oracle as orc
+from oracle_util import maxdiff, noise_from_fixture, oracle_render
+
+pytestmark = pytest.mark.gpu
+ALL = sorted(gu.CASES)
+TINY = [n for n in ALL if n.startswith("tiny")]
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_render_fp32_matches_reference(name):
+    from hip_util import setup
+    fx, spec, net, rend = setup(name, precision="fp32")
+    out = rend(net, _dev(fx["rays"]), want_weights=True)
+    span = max(spec["z_far"] - spec["z_near"], 1.0)
+    for lvl in ("coarse", "fine"):
+        if lvl == "fine" and spec["Kf"] == 0:
+            assert "fine" not in out
+            continue
+        assert maxdiff(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) <= 1e-4, lvl
+        assert maxdiff(out[lvl].weights.cpu(), fx[f"{lvl}_weights"]) <= 1e-4, lvl
+        assert maxdiff(out[lvl].depth.cpu(), fx[f"{lvl}_depth"]) <= 1e-4 * span * 4, lvl
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_point_mlp_fp32_matches_reference(name):
+    """PixelNeRFNet.forward (explicit points) == reference model output on the reference's own points."""
+    from hip_util import setup
+    fx, spec, net, rend = setup(name, precision="fp32")
+    for tag in ("coarse", "fine"):
+        if f"pts_xyz_{tag}" not in fx:
+            continue
+        out = net(_dev(fx[f"pts_xyz_{tag}"]), coarse=(tag == "coarse"), viewdirs=_dev(fx[f"pts_dirs_{tag}"]))
+        assert np.allclose(out.cpu().numpy(), fx[f"pts_out_{tag}"], rtol=2e-5, atol=5e-5), tag
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_stage_kernels_match_oracle(name):
+    from hip_util import setup
+    fx, spec, net, rend = setup(name)
+    res = oracle_render(fx)
+    rays = _dev(fx["rays"]).reshape(-1, 8)
+    # a2 sample_coarse
+    z = rend.sample_coarse(rays)
+    assert maxdiff(z.cpu(), res["coarse"]["z"]) <= 2e-6 * max(1.0, spec["z_far"])
+    # a4 composite on the oracle's model outputs
+    zc = res["coarse"]["z"].cuda()
+    w, rgb, depth = rend._composite_native(rays, zc.contiguous(), res["coarse"]["pts_out"].cuda().contiguous())
+    assert maxdiff(w.cpu(), res["coarse"]["weights"].reshape(w.shape)) <= 2e-6
+    assert maxdiff(rgb.cpu(), res["coarse"]["rgb"].reshape(rgb.shape)) <= 5e-6
+    assert maxdiff(depth.cpu(), res["coarse"]["depth"].reshape(-1)) <= 2e-5
+    # a5-a7 fine sampling + sort from the oracle's coarse weights/depth
+    if spec["Kf"] > 0:
+        rend.last_seed = 0
+        zf = rend.sample_fine_sorted(rays, zc, res["coarse"]["weights"].reshape(w.shape).cuda(),
+                                     res["coarse"]["depth"].reshape(-1).cuda())
+        assert maxdiff(zf.cpu(), res["fine"]["z"]) <= 5e-6 * max(1.0, spec["z_far"])
+        assert bool((zf[:, 1:] >= zf[:, :-1]).all())
+
+
+def test_generic_model_protocol():
+    """The renderer still drives an arbitrary Python model (reference protocol nerf.py:188,212-216)."""
+    from hip_util import setup
+    fx, spec, net, rend = setup("tiny_ns1")
+
+    class Toy(torch.nn.Module):
+        use_viewdirs = True
+
+        def forward(self, xyz, coarse=True, viewdirs=None):
+            s = torch.sin(xyz * 3.0).abs()
+            sig = (xyz.norm(dim=-1, keepdim=True) < 1.0).float() * (8.0 if coarse else 11.0) + viewdirs[..., :1].abs()
+            return torch.cat([s, sig], dim=-1)
+
+    toy = Toy()
+    rays = _dev(fx["rays"])
+    out = rend(toy, rays, want_weights=True)
+    # oracle: same stages with the toy model on CPU
+    n = noise_from_fixture(fx)
+    r = torch.from_numpy(fx["rays"]).reshape(-1, 8)
+    zc = orc.sample_coarse(r, spec["Kc"], spec["lindisp"], n["noise_c"])
+
+    def run(z, coarse):
+        K = z.shape[1]
+        pts = (r[:, None, :3] + z.unsqueeze(2) * r[:, None, 3:6]).reshape(1, -1, 3)
+        dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(1, -1, 3)
+        return orc.composite(r, z, toy(pts, coarse=coarse, viewdirs=dirs).reshape(-1, K, 4), spec["white_bkgd"])
+
+    w, rgb, depth = run(zc, True)
+    assert maxdiff(out.coarse.rgb.cpu().reshape(-1, 3), rgb) <= 1e-5
+    zf = torch.sort(torch.cat([zc, orc.sample_fine(r, w, spec["Kc"], spec["lindisp"], n["u"], n["r"]),
+                               orc.sample_fine_depth(r, depth, spec["depth_std"], n["g"])], -1), -1)[0]
+    w2, rgb2, depth2 = run(zf, False)
+    assert maxdiff(out.fine.rgb.cpu().reshape(-1, 3), rgb2) <= 1e-5
+    assert maxdiff(out.fine.weights.cpu().reshape(w2.shape), w2) <= 1e-5
+
+
+def test_kernel_rng_sharding_is_bit_identical():
+    """Counter-based noise keyed by the global ray index: rendering a frame in two shards (ray_index_base)
+    gives exactly the bytes of the unsharded frame."""
+    from hip_util import setup
+    fx, spec, net, rend = setup("tiny_ns2_codeview")
+    rend.fixed_noise = None
+    rays = _dev(fx["rays"])
+    torch.manual_seed(5)
+    full = rend(net, rays)
+    seed = rend.last_seed
+    h = rays.shape[1] // 2
+    parts = []
+    for lo, hi in ((0, h), (h, rays.shape[1])):
+        torch.manual_seed(5)
+        rend.ray_index_base = lo
+        parts.append(rend(net, rays[:, lo:hi].contiguous()))
+        assert rend.last_seed == seed
+    rend.ray_index_base = 0
+    assert torch.equal(torch.cat([p.fine.rgb for p in parts], 1), full.fine.rgb)
+    assert torch.equal(torch.cat([p.fine.depth for p in parts], 1), full.fine.depth)
+
+
+def test_kernel_rng_statistics():
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    rend = NeRFRenderer(n_coarse=64).cuda()
+    rays = torch.zeros(4096, 8, device="cuda")
+    rays[:, 6], rays[:, 7] = 0.0, 1.0
+    z = rend.sample_coarse(rays, seed=1234)
+    t = (z * 64 - torch.arange(64, device="cuda")[None]).flatten()      # the U[0,1) jitter
+    assert 0.0 <= float(t.min()) and float(t.max()) < 1.0 + 1e-4
+    assert abs(float(t.mean()) - 0.5) < 5e-3 and abs(float(t.var()) - 1 / 12) < 5e-3
+    z2 = rend.sample_coarse(rays, seed=1234)
+    assert torch.equal(z, z2)
+    assert not torch.equal(z, rend.sample_coarse(rays, seed=1235))
+
+
+def test_full_size_properties():
+    """BASELINE-size frame (128x128 rays, 64+32 samples): size-independent properties of the stages."""
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    N, Kc, Kf, Kfd = 16384, 64, 32, 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rays = torch.zeros(N, 8, device="cuda")
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    rays[:, 6], rays[:, 7] = 1.25, 2.75
+    rend = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, white_bkgd=True).cuda()
+    z = rend.sample_coarse(rays, seed=7)
+    assert bool((z[:, 1:] > z[:, :-1]).all()) and float(z.min()) >= 1.25 and float(z.max()) <= 2.75
+    out = torch.rand(N, Kc, 4, device="cuda", generator=g)
+    out[..., 3] *= 30.0
+    out[..., :3] = 1.0                                    # constant white colour
+    w, rgb, depth = rend._composite_native(rays, z, out)
+    assert float((rgb - 1.0).abs().max()) <= 1e-5         # sum w*1 + (1 - sum w) == 1
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+    assert bool(((depth >= 0) & (depth <= 2.75 + 1e-4)).all())
+    zf = rend.sample_fine_sorted(rays, z, w, depth, seed=7)
+    assert zf.shape == (N, Kc + Kf) and bool((zf[:, 1:] >= zf[:, :-1]).all())
+    assert float(zf.min()) >= 1.25 - 1e-5 and float(zf.max()) <= 2.75 + 1.5 / Kc + 1e-4   # i may equal Kc (a5)
+    # the merged set contains every coarse sample
+    merged = torch.sort(torch.cat([z, zf], -1), -1)[0]
+    assert merged.shape[1] == 2 * Kc + Kf
+
+
+def test_empty_and_error_paths():
+    from hip_util import setup
+    fx, spec, net, rend = setup("tiny_ns1")
+    wrapped = rend.bind_parallel(net, simple_output=True)
+    rgb, depth = wrapped(torch.zeros(0, 8, device="cuda"))
+    assert rgb.shape == (0, 3) and depth.shape == (0,)
+    with pytest.raises(RuntimeError):
+        rend(net, torch.from_numpy(fx["rays"]))           # CPU rays: no CPU path
+    with pytest.raises(ValueError):
+        rend(net, torch.zeros(3, 4, 8, device="cuda"))    # 3 objects vs 1 encoded

@@ -1,0 +1,126 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/pnr.h declares (no compute
+without a GPU), the ctypes structs match the header's layout, and the host logic mirrors the reference."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pixel_nerf_multiscale_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "pnr.h")).read()
+    declared = set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    assert declared == set(N.PROTOTYPES), declared ^ set(N.PROTOTYPES)
+    for name in declared:
+        assert hasattr(N.lib, name), name
+    assert N.lib.pnr_version() == 100
+    assert N.lib.pnr_error_string(-4).decode() == "workspace too small"
+
+
+def test_struct_layout_matches_header():
+    from pixel_nerf_multiscale_amd import _native as N
+    src = '#include <stdio.h>\n#include "pnr.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(pnr_mlp), sizeof(pnr_views), sizeof(pnr_params), sizeof(pnr_noise), sizeof(pnr_outputs));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(s) for s in (N.pnr_mlp, N.pnr_views, N.pnr_params, N.pnr_noise, N.pnr_outputs)]
+
+
+def test_null_and_shape_errors_without_gpu():
+    """Argument validation happens before any HIP call."""
+    from pixel_nerf_multiscale_amd import _native as N
+    assert N.lib.pnr_sample_coarse(None, 4, 8, 0, None, 0, 0, None, None) == -1
+    assert N.lib.pnr_composite(None, None, None, 4, 8, 0, None, None, None, None) == -1
+    assert N.lib.pnr_gen_rays(None, 4, 4, 1.0, 1.0, 2.0, 2.0, 0.1, 1.0, 0, 16, None, None) == -1
+    with pytest.raises(ValueError):
+        N.check(-2, "x")
+    with pytest.raises(RuntimeError):
+        N.ptr(torch.zeros(3))          # CPU tensors never reach the library
+
+
+def test_state_dict_keys_match_reference_layout():
+    from hip_util import model_conf
+    from pixel_nerf_multiscale_amd import PixelNeRFNet
+    spec = gu.CASES["full_ns1"]
+    net = PixelNeRFNet(model_conf(spec))
+    keys = set(net.state_dict().keys())
+    for which in ("mlp_coarse", "mlp_fine"):
+        for k, v in gu.make_mlp_state(spec, "coarse").items():
+            assert f"{which}.{k}" in keys
+            assert tuple(net.state_dict()[f"{which}.{k}"].shape) == v.shape
+    assert tuple(net.state_dict()["code._freqs"].shape) == (1, 12, 1)
+    assert tuple(net.state_dict()["code._phases"].shape) == (1, 12, 1)
+    assert "encoder.model.layer3.5.conv2.weight" in keys and "encoder.layers.0.0.weight" in keys
+    assert sum(p.numel() for p in net.mlp_coarse.parameters()) == 3045380
+    assert net.d_in == 42 and net.d_latent == 256 and net.latent_size == 256
+
+
+@pytest.mark.parametrize("name", ["tiny_ns2_lindisp_black", "tiny_sb2_ns2", "full_ns3"])
+def test_set_cameras_matches_reference_encode(name):
+    from hip_util import build_net
+    fx = gu.load_fixture(name)
+    net = build_net(fx["spec"], fx["poses"], device="cpu")
+    assert np.abs(net.poses.numpy() - fx["enc_w2c"]).max() < 1e-6
+    assert np.array_equal(net.focal.numpy(), fx["enc_focal"])
+    assert np.array_equal(net.c.numpy(), fx["enc_c"])
+    assert np.array_equal(net.image_shape.numpy(), fx["enc_image_shape"])
+
+
+def test_gen_rays_and_pose_spherical():
+    from pixel_nerf_multiscale_amd import util
+    c2w = util.pose_spherical(75.0, -25.0, 2.0)
+    ref = gu.pose_spherical(75.0, -25.0, 2.0)
+    assert np.abs(c2w.numpy() - ref).max() < 1e-6
+    W, H, f = 40, 30, 45.0
+    rays = util.gen_rays(c2w[None], W, H, torch.tensor(f), 1.25, 2.75)
+    assert rays.shape == (1, H, W, 8)
+    pix = np.arange(W * H)
+    ref_rays = gu.pinhole_rays(ref, W, H, f, 1.25, 2.75, pix)
+    assert np.abs(rays.reshape(-1, 8).numpy() - ref_rays).max() < 1e-6
+
+
+def test_renderer_surface_and_schedule():
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    r = NeRFRenderer.from_conf(dict(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True,
+                                    sched=[[2, 4], [16, 32], [8, 16]]), lindisp=False)
+    assert (r.n_coarse, r.n_fine, r.n_fine_depth, r.using_fine, r.eval_batch_size) == (64, 32, 16, True, 100000)
+    assert set(r.state_dict()) == {"iter_idx", "last_sched"} and r.iter_idx.dtype == torch.long
+    r.sched_step(1)
+    assert (r.n_coarse, r.n_fine) == (64, 32)
+    r.sched_step(1)
+    assert (r.n_coarse, r.n_fine, int(r.last_sched)) == (16, 8, 1)
+    r.sched_step(5)
+    assert (r.n_coarse, r.n_fine, int(r.last_sched)) == (32, 16, 2)
+    d = NeRFRenderer()
+    assert (d.n_coarse, d.n_fine, d.white_bkgd, d.lindisp, d.sched) == (128, 0, False, False, None)
+    with pytest.raises(NotImplementedError):
+        d.bind_parallel(None, gpus=[0, 1])
+
+
+def test_container_modules_do_not_evaluate_in_pytorch():
+    from pixel_nerf_multiscale_amd.model import ResnetFC, SpatialEncoder
+    with pytest.raises(RuntimeError):
+        ResnetFC(42, d_latent=8, d_hidden=32)(torch.zeros(2, 50))
+    enc = SpatialEncoder(pretrained=False)
+    with pytest.raises(RuntimeError):
+        enc.index(torch.zeros(1, 2, 2))
+    # the conv trunk itself is ordinary PyTorch (runs once per object, out of the hot path)
+    lat = enc(torch.zeros(1, 3, 64, 64))
+    assert lat.shape == (1, 256, 4, 4) and enc.latent_size == 256
+    ms = SpatialEncoder(pretrained=False, use_multi_scale=True, use_first_pool=False)
+    lats = ms(torch.zeros(2, 3, 64, 64))
+    assert [tuple(l.shape[1:]) for l in lats] == [(64, 32, 32), (64, 32, 32), (128, 16, 16), (256, 8, 8)]
