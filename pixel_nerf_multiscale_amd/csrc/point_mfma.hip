@@ -1,11 +1,670 @@
-// placeholder until the fused MFMA kernel lands
+// Fused per-point network for gfx950 (CDNA4): PixelNeRFNet.forward (models.py.backup2:155-282) + ResnetFC
+// (resnetfc.py:173-236) in ONE persistent kernel, bf16 or fp16 MFMA with fp32 accumulation.
+//
+// Shape of the computation (d_hidden = 512):
+//   * a workgroup = 4 waves (one per SIMD, up to 512 registers each) owns a tile of 128 points;
+//     a wave owns 32 of them: they are the 32 COLUMNS (lanes) of v_mfma_f32_32x32x16.
+//   * activations are kept TRANSPOSED, X^T = [512 features x 32 points] fp32, as 16 accumulator tiles
+//     (256 registers) for the whole network: Y^T = W . X^T uses the PyTorch (out,in) weight as the A operand
+//     and the previous layer's accumulators, converted in registers to bf16, as the B operand — the sum runs
+//     over the accumulator's ROW index, so no lane movement and no LDS round trip for activations.
+//   * the weights of the whole MLP are pre-packed (pnr_pack_mlp) into a linear stream of 1-KiB MFMA A-fragments in
+//     exactly the order the kernel consumes them; all 4 waves consume the same stream, so it is staged through a
+//     4-slot x 16-KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4) two stages ahead, one barrier per stage
+//     of 16 MFMAs.  Every workgroup streams the same bytes in the same order => L2-resident across the XCD.
+//   * pixel-aligned features: each lane projects its point, gathers 4 bilinear taps from the channels-last 16-bit
+//     latent copy and writes the interpolated channels straight into the wave's LDS B-fragment image.
+//   * multi-view: the first `combine_layer` blocks run once per source view on the same 128 points; the per-view
+//     residual streams are parked in a caller-provided workspace and reduced (mean/max) in registers.
 #include "pnr_common.h"
+
 namespace pnr {
-uint64_t point_mfma_workspace_bytes(const pnr_mlp*, const pnr_views*) { return 256; }
-int32_t point_mfma(const pnr_params*, const pnr_mlp*, const pnr_views*, PointSrc, int64_t, int64_t, float*, void*,
-                   uint64_t, hipStream_t) { return PNR_E_UNSUPPORTED; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // one 16-bit x8 MFMA operand fragment
+
+static constexpr int HID = 512;          // d_hidden the kernel is specialised for
+static constexpr int NT = HID / 32;      // 16 feature tiles of 32 rows
+static constexpr int STAGE_BYTES = 16384;
+static constexpr int RING_SLOTS = 5;     // >= PREFETCH + 3 (one published stage is read ahead into registers)
+static constexpr int PREFETCH = 2;       // stages in flight beyond the one being consumed
+static constexpr int TILE_PTS = 128;
+static constexpr int ZBUF_BYTES = 16384; // per wave: 16 k-steps x 64 lanes x 16 B (256 latent channels)
+static constexpr int LDS_RING = 0;
+static constexpr int LDS_Z = RING_SLOTS * STAGE_BYTES;
+static constexpr int LDS_BTAB = LDS_Z + 4 * ZBUF_BYTES;
+
+// ---------------------------------------------------------------------------- 16-bit helpers
+template <int DT> struct Num;
+template <> struct Num<PNR_BF16> {
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        f32x2 f = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));      // v_cvt_pk_bf16_f32
+    }
+    static __device__ __forceinline__ float lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+    static __device__ __forceinline__ float hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+    static __device__ __forceinline__ uint16_t one() { return 0x3F80; }
+    static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
+    static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
+    static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Num<PNR_F16> {
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        f32x2 f = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));       // v_cvt_pk_f16_f32
+    }
+    static __device__ __forceinline__ float lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+    static __device__ __forceinline__ uint16_t one() { return 0x3C00; }
+    static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
+    static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
+    static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+// relu on two packed 16-bit floats: negative <=> sign bit <=> negative as int16 (v_pk_max_i16 with 0)
+__device__ __forceinline__ uint32_t relu_pk(uint32_t p) {
+    s16x2 v = __builtin_bit_cast(s16x2, p);
+    s16x2 z = {0, 0};
+    v = __builtin_elementwise_max(v, z);
+    return __builtin_bit_cast(uint32_t, v);
 }
-extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp*) { return 0; }
-extern "C" int32_t pnr_pack_mlp(const pnr_mlp*, int32_t, void*, uint64_t, void*) { return PNR_E_UNSUPPORTED; }
-extern "C" uint64_t pnr_packed_latent_bytes(const pnr_views*) { return 0; }
-extern "C" int32_t pnr_pack_latents(const pnr_views*, int32_t, void*, uint64_t, void*) { return PNR_E_UNSUPPORTED; }
+
+// ---------------------------------------------------------------------------- stream layout (shared by pack + kernel)
+// Stage = 16 fragments of 1 KiB.  Per (tile, view):  LIN_IN (S_in stages), then per phase-1 block
+// [LIN_Z: SZ stages + 1 bias stage] [fc_1 bias stage] [16 chunks x (2 fc_0 + 2 fc_1 stages)];
+// phase 2: per block [fc_1 bias stage][16 x 4]; LIN_OUT 2 stages.
+struct Layout {
+    int d_in, d_in_pad, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats;
+    uint64_t btab_bytes, stream_bytes, total_bytes;
+};
+static constexpr int BLOCK_STAGES = 1 + 16 * 4;
+
+__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y) {
+    if (m.d_hidden != HID || m.d_out != 4 || m.d_latent <= 0 || (m.d_latent % 256) != 0 || m.d_latent > 1024) return false;
+    if (m.n_blocks < 1 || m.n_blocks > PNR_MAX_BLOCKS || m.d_in < 1 || m.d_in > 78) return false;
+    y.d_in = m.d_in;
+    y.d_in_pad = ((m.d_in + 2 + 15) / 16) * 16;     // two spare k-slots carry the folded lin_in bias (hi, lo)
+    y.S_in = y.d_in_pad / 16;
+    if (y.S_in > 5) return false;
+    y.L = m.d_latent;
+    y.SZ = m.d_latent / 16;
+    y.n_blocks = m.n_blocks;
+    y.nb1 = m.combine_layer < m.n_blocks ? m.combine_layer : m.n_blocks;
+    if (y.nb1 < 0) y.nb1 = 0;
+    y.nb2 = m.n_blocks - y.nb1;
+    y.P1 = y.S_in + y.nb1 * (y.SZ + 1 + BLOCK_STAGES);
+    y.P2 = y.nb2 * BLOCK_STAGES + 2;
+    y.btab_floats = ((m.n_blocks * HID + 4 + 63) / 64) * 64;
+    y.btab_bytes = (uint64_t)y.btab_floats * 4;
+    y.stream_bytes = (uint64_t)(y.P1 + y.P2) * STAGE_BYTES;
+    y.total_bytes = y.btab_bytes + y.stream_bytes;
+    return true;
+}
+
+// accumulator-row permutation of the 32x32 MFMA: B/A element j of lane half h in k-step s of a 32-row tile
+// is feature row 16 s + 8 (j>>2) + 4 h + (j&3)
+__host__ __device__ inline int perm_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---------------------------------------------------------------------------- pack kernels
+template <int DT>
+__global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out) {
+    // bias table
+    float* bt = (float*)out;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < y.btab_floats; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < m.n_blocks * HID) v = m.fc0_b[i / HID][i % HID];
+        else if (i < m.n_blocks * HID + 4) v = m.lin_out_b[i - m.n_blocks * HID];
+        bt[i] = v;
+    }
+    uint16_t* st = (uint16_t*)(out + y.btab_bytes);
+    const int64_t n_elems = (int64_t)(y.P1 + y.P2) * 16 * 64 * 8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(e & 7), lane = (int)((e >> 3) & 63), f = (int)((e >> 9) & 15);
+        int stage = (int)(e >> 13);
+        int r = lane & 31, h = lane >> 5;
+        float val = 0.f;
+        // ---- locate the stage
+        int s = stage;
+        bool done = false;
+        if (s < y.S_in) {                               // LIN_IN: natural k, bias folded at k = d_in (hi), d_in+1 (lo)
+            int n = 32 * f + r, k = 16 * s + 8 * h + j;
+            if (k < m.d_in) val = m.lin_in_w[(size_t)n * m.d_in + k];
+            else if (k == m.d_in) val = m.lin_in_b[n];
+            else if (k == m.d_in + 1) val = m.lin_in_b[n] - Num<DT>::back(Num<DT>::cvt(m.lin_in_b[n]));
+            done = true;
+        } else s -= y.S_in;
+        int b = 0;
+        if (!done) {
+            const int per1 = y.SZ + 1 + BLOCK_STAGES;
+            int in_blk;
+            if (stage < y.P1) { b = s / per1; in_blk = s % per1; }
+            else {
+                int s2 = stage - y.P1;
+                if (s2 >= y.nb2 * BLOCK_STAGES) {       // LIN_OUT: 2 stages, rows 0..3 valid
+                    int hf = s2 - y.nb2 * BLOCK_STAGES;
+                    int t = 8 * hf + (f >> 1), sk = f & 1;
+                    int k = 32 * t + perm_k(sk, h, j);
+                    if (r < 4) val = m.lin_out_w[(size_t)r * HID + k];
+                    in_blk = -1;
+                } else { b = y.nb1 + s2 / BLOCK_STAGES; in_blk = y.SZ + 1 + s2 % BLOCK_STAGES; }
+            }
+            if (in_blk >= 0) {
+                if (in_blk < y.SZ) {                    // LIN_Z k-step in_blk: natural k
+                    int n = 32 * f + r, k = 16 * in_blk + 8 * h + j;
+                    val = m.lin_z_w[b][(size_t)n * y.L + k];
+                } else if (in_blk == y.SZ || in_blk == y.SZ + 1) {   // bias stages: k-slot 0 = hi, 1 = lo
+                    const float* bp = (in_blk == y.SZ) ? m.lin_z_b[b] : m.fc1_b[b];
+                    int n = 32 * f + r;
+                    if (h == 0 && j == 0) val = bp[n];
+                    else if (h == 0 && j == 1) val = bp[n] - Num<DT>::back(Num<DT>::cvt(bp[n]));
+                } else {
+                    int q = in_blk - (y.SZ + 2);        // 0..63
+                    int c = q >> 2, part = q & 3;
+                    if (part < 2) {                     // fc_0 chunk c: rows 32c.., k tiles t = 8*part + f/2
+                        int t = 8 * part + (f >> 1), sk = f & 1;
+                        val = m.fc0_w[b][(size_t)(32 * c + r) * HID + 32 * t + perm_k(sk, h, j)];
+                    } else {                            // fc_1 chunk c: output tiles tn = 8*(part-2) + f/2, k in chunk c
+                        int tn = 8 * (part - 2) + (f >> 1), sk = f & 1;
+                        val = m.fc1_w[b][(size_t)(32 * tn + r) * HID + 32 * c + perm_k(sk, h, j)];
+                    }
+                }
+            }
+        }
+        st[e] = Num<DT>::cvt(val);
+    }
+}
+
+struct LatPack { uint64_t off[PNR_MAX_LEVELS]; uint64_t total; };
+__host__ __device__ inline LatPack lat_layout(const pnr_views& v) {
+    LatPack p; uint64_t o = 0;
+    int nv = v.n_objs * v.n_views;
+    for (int i = 0; i < PNR_MAX_LEVELS; ++i) {
+        p.off[i] = o;
+        if (i < v.n_levels) o += (((uint64_t)nv * v.lat_c[i] * v.lat_h[i] * v.lat_w[i] * 2) + 255) & ~(uint64_t)255;
+    }
+    p.total = o + 64;   // tail pad: 16-B tap loads never run past the allocation
+    return p;
+}
+
+template <int DT>
+__global__ void k_pack_latents(pnr_views v, LatPack lp, char* __restrict__ out) {
+    int nv = v.n_objs * v.n_views;
+    for (int lvl = 0; lvl < v.n_levels; ++lvl) {
+        int C = v.lat_c[lvl], HW = v.lat_h[lvl] * v.lat_w[lvl];
+        int64_t n = (int64_t)nv * C * HW;
+        uint16_t* o = (uint16_t*)(out + lp.off[lvl]);
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+            int c = (int)(e % C); int64_t t = e / C; int px = (int)(t % HW); int view = (int)(t / HW);
+            o[e] = Num<DT>::cvt(v.latent[lvl][((size_t)view * C + c) * HW + px]);     // (view, px, c) <- (view, c, px)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- the fused kernel
+struct MfmaArgs {
+    pnr_views vw;
+    PointSrc src;
+    int64_t n_points, pts_per_obj;
+    const char* stream;
+    const float* btab;
+    const char* lat;               // packed latents
+    uint64_t lat_off[PNR_MAX_LEVELS];
+    float* out;
+    float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
+    int n_tiles, NS, combine_max;
+    int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in;
+    int use_code_viewdirs, num_freqs;
+    float freq_factor;
+};
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// 4 x 1 KiB LDS-DMA (global_load_lds_dwordx4) of one wave's quarter of a stage: lane l moves 16 B from
+// g + 1024 q + 16 l to LDS dst + 1024 q + 16 l.  Inline asm so that hipcc neither counts these loads in its own
+// vmcnt bookkeeping nor drains them before barriers / ds_reads; they are retired by the counted s_waitcnt in
+// begin_stage (cdna_hip_programming.md §5.7).  The instruction offset applies to both addresses.
+__device__ __forceinline__ void glds_quarter(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+}
+
+template <int DT, bool MULTIVIEW>
+__global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Num<DT> NM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    float* btab = (float*)(smem + LDS_BTAB);
+    for (int i = tid; i < a.btab_floats; i += 256) btab[i] = a.btab[i];
+    __syncthreads();
+
+    // ---------------- weight-stream loader: every wave issues 4 x 1 KiB LDS-DMA per stage, PREFETCH+1 stages ahead
+    int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
+    const uint32_t gl_off = (uint32_t)(wv * 4096 + lane * 16);
+    const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
+    auto issue_stage = [&]() {
+        glds_quarter(a.stream + (size_t)ld_idx * STAGE_BYTES, gl_off,
+                     __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES));
+        ld_slot = (ld_slot + 1 == RING_SLOTS) ? 0 : ld_slot + 1;
+        ++ld_idx;
+        if (ld_rep < a.NS) {
+            if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
+        } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
+    };
+    // Stage protocol.  On entry to stage i its fragments are already PUBLISHED (all waves' DMA landed + a barrier
+    // passed) and its first 8 fragments sit in registers A[0..7].  begin_stage(): start the DMA of stage
+    // i+PREFETCH+1, wait until this wave's DMA of stage i+1 has landed, barrier => stage i+1 is published and
+    // may be read (prefetched into A) during stage i.  A slot is rewritten RING_SLOTS stages later; the readers of
+    // its previous content (stage i-2 and older) have all passed two barriers since.  RING_SLOTS >= PREFETCH + 3.
+    frag_t A[8];
+    const char* cur;    // this lane's read base of the stage being consumed
+    const char* nxt;    // ... of the next stage
+    auto begin_stage = [&]() {
+        issue_stage();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // 4 x PREFETCH younger loads may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
+        st_slot = (st_slot + 1 == RING_SLOTS) ? 0 : st_slot + 1;
+        nxt = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
+    };
+    // fragment f of the current stage is in A[f & 7]; after using it, refill the register 8 fragments ahead
+#define PNR_REFILL(f) A[(f) & 7] = *(const frag_t*)(((f) < 8 ? cur : nxt) + (((f) + 8) & 15) * 1024)
+
+#pragma unroll
+    for (int i = 0; i < PREFETCH + 1; ++i) issue_stage();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A[f] = *(const frag_t*)(smem + LDS_RING + lane * 16 + f * 1024);
+
+    f32x16 x[NT];          // X^T: 16 tiles of [32 features x 32 points], fp32 residual stream
+    frag_t xb[NT][2];       // relu(X^T) as 16-bit B fragments (k-steps 0,1 of every tile)
+    const uint32_t one2 = (uint32_t)NM::one() | ((uint32_t)NM::one() << 16);
+    const frag_t b_bias = {h == 0 ? one2 : 0u, 0u, 0u, 0u};   // k-slots 0,1 = 1.0: picks (hi, lo) of a bias fragment
+    char* zwave = smem + LDS_Z + wv * ZBUF_BYTES;
+
+    auto stage_x = [&](frag_t B) {                 // x[tn] += A_tn . B for the 16 output tiles
+        begin_stage();
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            x[f] = NM::mfma(A[f & 7], B, x[f]);
+            PNR_REFILL(f);
+        }
+    };
+    // n_lds k-steps whose B fragment is image [k-step][lane] in this wave's LDS buffer, then n_bias bias stages
+    auto x_stages = [&](int n_lds, int n_bias) {
+        frag_t Bz = *(const frag_t*)(zwave + lane * 16);
+#pragma unroll 1
+        for (int it = 0; it < n_lds + n_bias; ++it) {
+            const frag_t Bn = *(const frag_t*)(zwave + ((it + 1) & 15) * 1024 + lane * 16);
+            stage_x(it < n_lds ? Bz : b_bias);
+            Bz = Bn;
+        }
+    };
+    auto snapshot = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                frag_t v;
+                v.x = relu_pk(NM::pack(x[t][8 * s + 0], x[t][8 * s + 1]));
+                v.y = relu_pk(NM::pack(x[t][8 * s + 2], x[t][8 * s + 3]));
+                v.z = relu_pk(NM::pack(x[t][8 * s + 4], x[t][8 * s + 5]));
+                v.w = relu_pk(NM::pack(x[t][8 * s + 6], x[t][8 * s + 7]));
+                xb[t][s] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one 32-row chunk of a [.. x 512] product against xb: acc = W[chunk rows] . relu(X)   (2 stages)
+    // hipcc gives every MFMA of a kernel that needs AGPRs the AGPR form, and all 256 AGPRs hold X^T: for this chain it
+    // parks one X^T tile in VGPRs (v_accvgpr_read/write, hidden under the MFMAs).  A VGPR-form inline-asm chain was
+    // tried and is wrong by construction: the register allocator may put v_mov copies of the accumulator between two
+    // asm statements, and nothing pads the MFMA->VALU hazard for it.
+    auto chunk_from_xb = [&](f32x16 acc) -> f32x16 {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            begin_stage();
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc = NM::mfma(A[f & 7], xb[8 * half + (f >> 1)][f & 1], acc);
+                PNR_REFILL(f);
+            }
+        }
+        return acc;
+    };
+    auto load_hbias = [&](int b, int c) -> f32x16 {   // fc_0.bias rows of chunk c in accumulator row order
+        f32x16 hacc;
+        const float* bp = btab + b * HID + 32 * c + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = *(const float4*)(bp + 8 * q);
+            hacc[4 * q + 0] = v.x; hacc[4 * q + 1] = v.y; hacc[4 * q + 2] = v.z; hacc[4 * q + 3] = v.w;
+        }
+        return hacc;
+    };
+
+    const int n_groups = a.SZ / 16;               // latent channel groups of 256 (the LDS image holds one)
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t g = (int64_t)tile * TILE_PTS + wv * 32 + r;
+        const bool live = g < a.n_points;
+        const int64_t gc = live ? g : a.n_points - 1;
+        const int obj = (int)(gc / a.pts_per_obj);
+        float pu = 0.f, pv = 0.f;
+        int v = 0, b = 0, view = 0;
+        bool start = true;
+
+        // ---- latent gather: group grp (256 channels) -> this wave's LDS B-fragment image [k-step][lane][8]
+        auto gather = [&](int grp) {
+            int ch0 = 0;
+            for (int lvl = 0; lvl < a.vw.n_levels; ++lvl) {
+                const int C = a.vw.lat_c[lvl], W = a.vw.lat_w[lvl], H = a.vw.lat_h[lvl];
+                const int lo = ch0 > grp * 256 ? ch0 : grp * 256;
+                const int hi = (ch0 + C) < (grp + 1) * 256 ? (ch0 + C) : (grp + 1) * 256;
+                if (lo < hi) {
+                    const Taps tp = bilinear_taps(pu, pv, W, H);
+                    const char* lb = a.lat + a.lat_off[lvl] + (size_t)view * H * W * C * 2;
+                    for (int ch = lo + 8 * h; ch < hi; ch += 16) {
+                        float acc8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint4 q = *(const uint4*)(lb + ((size_t)tp.off[i] * C + (ch - ch0)) * 2);
+                            const float w = tp.w[i];
+                            acc8[0] += NM::lo(q.x) * w; acc8[1] += NM::hi(q.x) * w;
+                            acc8[2] += NM::lo(q.y) * w; acc8[3] += NM::hi(q.y) * w;
+                            acc8[4] += NM::lo(q.z) * w; acc8[5] += NM::hi(q.z) * w;
+                            acc8[6] += NM::lo(q.w) * w; acc8[7] += NM::hi(q.w) * w;
+                        }
+                        uint4 o;
+                        o.x = NM::pack(acc8[0], acc8[1]); o.y = NM::pack(acc8[2], acc8[3]);
+                        o.z = NM::pack(acc8[4], acc8[5]); o.w = NM::pack(acc8[6], acc8[7]);
+                        const int ks = (ch - grp * 256) >> 4;
+                        *(uint4*)(zwave + ks * 1024 + lane * 16) = o;
+                    }
+                }
+                ch0 += C;
+            }
+        };
+
+        while (true) {
+            if (start) {
+                start = false;
+                // ---- per-view geometry (models.py.backup2:166-221)
+                view = obj * a.NS + v;
+                const Cam cam = load_cam(a.vw, view);
+                float p[3], d[3], xr[3], dr[3];
+                fetch_point(a.src, gc, p, d);
+                rot3(cam.R, p, xr);
+                rot3(cam.R, d, dr);
+                project(cam, xr, pu, pv);
+                // ---- positional features -> wave-private LDS image [k-step][half][col][8] (16-bit), natural k.
+                //      Lane half h writes the phase-h terms (sin for h=0, sin(.+pi/2) for h=1): uniform code.
+                {
+                    uint16_t* fz = (uint16_t*)zwave;
+                    for (int i = lane; i < 5 * 64 * 4; i += 64) ((uint32_t*)zwave)[i] = 0u;     // 5 KiB
+                    const int dcode = a.use_code_viewdirs ? 6 : 3;
+                    auto put = [&](int k, float val) {
+                        fz[(((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + r) * 8 + (k & 7)] = NM::cvt(val);
+                    };
+                    const float ph = h ? 1.57079637f : 0.0f;
+                    for (int i = 0; i < dcode; ++i) {
+                        const float xi = i == 0 ? xr[0] : i == 1 ? xr[1] : i == 2 ? xr[2] : i == 3 ? dr[0] : i == 4 ? dr[1] : dr[2];
+                        if (h == 0) put(i, xi);
+                        float f = a.freq_factor;
+                        for (int q = 0; q < a.num_freqs; ++q) {
+                            put(dcode + (2 * q + h) * dcode + i, __sinf(fmaf(xi, f, ph)));
+                            f *= 2.0f;
+                        }
+                    }
+                    if (!a.use_code_viewdirs && h == 1) {
+                        const int k0 = 3 + 6 * a.num_freqs;
+                        put(k0, dr[0]); put(k0 + 1, dr[1]); put(k0 + 2, dr[2]);
+                    }
+                    if (h == 0) { put(a.d_in, 1.0f); put(a.d_in + 1, 1.0f); }     // folded lin_in bias (hi, lo)
+                }
+                // ---- LIN_IN: x = W_in . features
+                {
+                    f32x16 zero;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) x[t] = zero;
+                }
+                x_stages(a.S_in, 0);
+                if (n_groups == 1) gather(0);
+            }
+            // ---- x += lin_z[b](z)  (blocks before the view reduction only)
+            if (b < a.nb1) {
+                for (int grp = 0; grp < n_groups; ++grp) {
+                    if (n_groups > 1) gather(grp);
+                    x_stages(16, grp == n_groups - 1 ? 1 : 0);       // last group: + lin_z.bias
+                }
+            }
+            // ---- resblock: x += fc_1(relu(fc_0(relu(x)))) + biases  (resnetfc.py:53-62)
+            snapshot();
+            x_stages(0, 1);                       // + fc_1.bias
+            {
+                f32x16 hacc = load_hbias(b, 0);
+#pragma unroll 1
+                for (int c = 0; c < 16; ++c) {
+                    hacc = chunk_from_xb(hacc);
+                    frag_t hb[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        hb[s].x = relu_pk(NM::pack(hacc[8 * s + 0], hacc[8 * s + 1]));
+                        hb[s].y = relu_pk(NM::pack(hacc[8 * s + 2], hacc[8 * s + 3]));
+                        hb[s].z = relu_pk(NM::pack(hacc[8 * s + 4], hacc[8 * s + 5]));
+                        hb[s].w = relu_pk(NM::pack(hacc[8 * s + 6], hacc[8 * s + 7]));
+                    }
+                    hacc = load_hbias(b, (c + 1) & 15);          // next chunk's bias while fc_1 runs
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        begin_stage();
+#pragma unroll
+                        for (int f = 0; f < 16; ++f) {
+                            const int tn = 8 * half + (f >> 1);
+                            x[tn] = NM::mfma(A[f & 7], hb[f & 1], x[tn]);
+                            PNR_REFILL(f);
+                        }
+                    }
+                }
+            }
+            ++b;
+            // ---- multi-view reduction after the last per-view block (util.combine_interleaved, util.py:466-476)
+            if (MULTIVIEW && b == a.nb1 && a.NS > 1) {
+                // pointers are stepped through an opaque asm so that hipcc does not hoist 64+ precomputed addresses
+                // out of the tile loop (they would be spilled around the MFMA loops)
+                float4* pp = a.spill + ((size_t)(blockIdx.x * 4 + wv) * (a.NS - 1)) * 4096 + lane;
+                if (v < a.NS - 1) {
+                    pp += (size_t)v * 4096;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            asm volatile("" : "+v"(pp));
+                            *pp = make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+                            pp += 64;
+                        }
+                    ++v; b = 0; start = true;
+                    continue;
+                }
+                const float inv = 1.0f / (float)a.NS;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(pp));
+                        float4 acc = *pp;
+                        for (int u = 1; u < a.NS - 1; ++u) {
+                            float4 o = pp[(size_t)u * 4096];
+                            if (a.combine_max) { acc.x = fmaxf(acc.x, o.x); acc.y = fmaxf(acc.y, o.y); acc.z = fmaxf(acc.z, o.z); acc.w = fmaxf(acc.w, o.w); }
+                            else { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+                        }
+                        pp += 64;
+                        if (a.combine_max) {
+                            x[t][4 * q] = fmaxf(acc.x, x[t][4 * q]); x[t][4 * q + 1] = fmaxf(acc.y, x[t][4 * q + 1]);
+                            x[t][4 * q + 2] = fmaxf(acc.z, x[t][4 * q + 2]); x[t][4 * q + 3] = fmaxf(acc.w, x[t][4 * q + 3]);
+                        } else {
+                            x[t][4 * q] = (acc.x + x[t][4 * q]) * inv; x[t][4 * q + 1] = (acc.y + x[t][4 * q + 1]) * inv;
+                            x[t][4 * q + 2] = (acc.z + x[t][4 * q + 2]) * inv; x[t][4 * q + 3] = (acc.w + x[t][4 * q + 3]) * inv;
+                        }
+                    }
+            }
+            if (b == a.n_blocks) break;
+        }
+
+        // ---- lin_out(relu(x)), sigmoid / relu (models.py.backup2:274-281)
+        snapshot();
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        if (h == 0) {
+            const float* bo = btab + a.n_blocks * HID;
+            o[0] = bo[0]; o[1] = bo[1]; o[2] = bo[2]; o[3] = bo[3];
+        }
+        o = chunk_from_xb(o);
+        if (h == 0 && live) {                     // rows 0..3 of the output tile sit in registers 0..3 of lanes 0..31
+            float4 res;
+            res.x = 1.0f / (1.0f + __expf(-o[0]));
+            res.y = 1.0f / (1.0f + __expf(-o[1]));
+            res.z = 1.0f / (1.0f + __expf(-o[2]));
+            res.w = fmaxf(o[3], 0.f);
+            ((float4*)a.out)[g] = res;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead LDS-DMA before the LDS is released
+    asm volatile("" :: "v"(A[0].x), "v"(A[1].x), "v"(A[2].x), "v"(A[3].x), "v"(A[4].x), "v"(A[5].x), "v"(A[6].x), "v"(A[7].x));
+}
+#undef PNR_REFILL
+
+// ---------------------------------------------------------------------------- host side
+static int num_cus() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    }
+    return n > 0 ? n : 256;
+}
+static constexpr int MAX_GRID = 512;
+
+uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
+    uint64_t b = 256;
+    if (vw->n_views > 1) b += (uint64_t)MAX_GRID * 4 * (vw->n_views - 1) * 4096 * sizeof(float4);
+    return b;
+}
+
+int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
+                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
+    Layout y;
+    if (!make_layout(*mlp, y)) return PNR_E_UNSUPPORTED;
+    if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
+    if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
+    LatPack lp = lat_layout(*vw);
+    if (!vw->latent_packed || vw->packed_dtype != prm->precision || vw->latent_packed_bytes < lp.total) return PNR_E_PACKED;
+    if (((uintptr_t)vw->latent_packed & 15) != 0) return PNR_E_ALIGN;
+    for (int i = 0; i < vw->n_levels; ++i)
+        if (vw->lat_c[i] % 16 != 0) return PNR_E_UNSUPPORTED;
+    if (ws_bytes < point_mfma_workspace_bytes(mlp, vw)) return PNR_E_WORKSPACE;
+    if (vw->n_views > 1 && y.nb1 == 0) return PNR_E_UNSUPPORTED;     // reduction before the first block
+    if (prm->use_code_viewdirs ? (mlp->d_in != 6 + 12 * prm->num_freqs) : (mlp->d_in != 6 + 6 * prm->num_freqs)) return PNR_E_SHAPE;
+
+    MfmaArgs a;
+    a.vw = *vw; a.src = src; a.n_points = n_points; a.pts_per_obj = pts_per_obj;
+    a.btab = (const float*)mlp->packed;
+    a.stream = (const char*)mlp->packed + y.btab_bytes;
+    a.lat = (const char*)vw->latent_packed;
+    for (int i = 0; i < PNR_MAX_LEVELS; ++i) a.lat_off[i] = lp.off[i];
+    a.out = out;
+    a.spill = (float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
+    a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
+    a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;
+    a.btab_floats = y.btab_floats; a.d_in = mlp->d_in;
+    a.use_code_viewdirs = prm->use_code_viewdirs; a.num_freqs = prm->num_freqs; a.freq_factor = prm->freq_factor;
+    int grid = num_cus();
+    if (grid > MAX_GRID) grid = MAX_GRID;
+    if (grid > a.n_tiles) grid = a.n_tiles;
+    const size_t lds = LDS_BTAB + (size_t)y.btab_floats * 4;
+    const void* fn;
+    const bool mv = a.NS > 1;
+    if (prm->precision == PNR_BF16) fn = mv ? (const void*)k_point_mfma<PNR_BF16, true> : (const void*)k_point_mfma<PNR_BF16, false>;
+    else fn = mv ? (const void*)k_point_mfma<PNR_F16, true> : (const void*)k_point_mfma<PNR_F16, false>;
+    PNR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {(void*)&a};
+    PNR_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, s));
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
+    Layout y;
+    if (!mlp || !make_layout(*mlp, y)) return 0;
+    return y.total_bytes;
+}
+
+extern "C" int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream) {
+    if (!mlp || !out) return PNR_E_NULL;
+    Layout y;
+    if (!make_layout(*mlp, y)) return PNR_E_UNSUPPORTED;
+    if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
+    if (out_bytes < y.total_bytes) return PNR_E_WORKSPACE;
+    if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    if (!mlp->lin_in_w || !mlp->lin_in_b || !mlp->lin_out_w || !mlp->lin_out_b) return PNR_E_NULL;
+    for (int b = 0; b < mlp->n_blocks; ++b) {
+        if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
+        if (b < y.nb1 && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
+    }
+    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out);
+    else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+extern "C" uint64_t pnr_packed_latent_bytes(const pnr_views* views) {
+    if (!views || views->n_levels < 1 || views->n_levels > PNR_MAX_LEVELS) return 0;
+    return lat_layout(*views).total;
+}
+
+extern "C" int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes, void* stream) {
+    if (!views || !out) return PNR_E_NULL;
+    if (views->n_levels < 1 || views->n_levels > PNR_MAX_LEVELS) return PNR_E_SHAPE;
+    if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
+    for (int i = 0; i < views->n_levels; ++i) if (!views->latent[i]) return PNR_E_NULL;
+    LatPack lp = lat_layout(*views);
+    if (out_bytes < lp.total) return PNR_E_WORKSPACE;
+    if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_latents<PNR_BF16>, dim3(1024), dim3(256), 0, (hipStream_t)stream, *views, lp, (char*)out);
+    else hipLaunchKernelGGL(k_pack_latents<PNR_F16>, dim3(1024), dim3(256), 0, (hipStream_t)stream, *views, lp, (char*)out);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
