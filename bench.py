@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: rendered rays/s at 128 samples/ray, SRN-chairs-shaped 1-view frame (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (NeRFRenderer.forward -> pnr_render: coarse sampling, fused point network,
+alpha compositing) over one frame of synthetic rays already resident in HBM.  With N ranks each rank renders its
+own contiguous range of an N x larger ray batch (weak scaling) and one RCCL all_gather per step reassembles the
+pixels (pixel_nerf_multiscale_amd.parallel.ShardedRenderer).  Rank 0 prints ONE JSON line with the
+whole-job throughput, the roofline of the dominant kernel (hipEvents around it, recorded by the library on the
+stream it runs on) and a CPU baseline (the oracle restatement timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: image side, Kc, Kf, Kfd, NS, latent levels (C,H,W), focal, radius, z_near, z_far, white, lindisp, code_viewdirs
+    "srn_chairs_1view_128x128_k128": dict(side=128, Kc=128, Kf=0, Kfd=0, NS=1, lat=[(256, 8, 8)], focal=131.25,
+                                          radius=2.0, z=(1.25, 2.75), white=True, lindisp=False, cv=False),
+    "srn_chairs_1view_128x128_k64+32": dict(side=128, Kc=64, Kf=32, Kfd=16, NS=1, lat=[(256, 8, 8)], focal=131.25,
+                                            radius=2.0, z=(1.25, 2.75), white=True, lindisp=False, cv=False),
+    "nmr_3view_64x64_k64+32": dict(side=64, Kc=64, Kf=32, Kfd=16, NS=3, lat=[(256, 8, 8)], focal=120.0,
+                                   radius=2.7, z=(1.2, 4.0), white=True, lindisp=False, cv=False),
+    "multiscale_cars_2view_128x128_k64+32": dict(side=128, Kc=64, Kf=32, Kfd=16, NS=2,
+                                                 lat=[(64, 64, 64), (64, 64, 64), (128, 32, 32), (256, 16, 16)],
+                                                 focal=131.25, radius=1.3, z=(0.8, 1.8), white=True, lindisp=False, cv=True),
+}
+DEFAULT = "srn_chairs_1view_128x128_k128"
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
+    """Algorithmic FLOPs of PixelNeRFNet.forward per query point: per (point, view)
+    lin_in + lin_z x3 + 3 blocks, then 2 blocks + lin_out per point."""
+    per_view = d_in * d_hidden + combine_layer * L * d_hidden + combine_layer * 2 * d_hidden * d_hidden
+    per_pt = (n_blocks - combine_layer) * 2 * d_hidden * d_hidden + 4 * d_hidden
+    return 2 * (NS * per_view + per_pt)
+
+
+def build(workload, precision, device, rank_rays_scale=1, seed=0):
+    """Random-init network of the reference architecture + synthetic latents/cameras/rays (no dataset, no checkpoint)."""
+    import golden_util as gu
+    from hip_util import build_net, build_renderer
+    w = WORKLOADS[workload]
+    spec = dict(gu._BASE)
+    spec.update(seed=100 + seed, d_hidden=512, lat=w["lat"], NS=w["NS"], SB=1, image=(w["side"], w["side"]),
+                focal=w["focal"], N=0, Kc=w["Kc"], Kf=w["Kf"], Kfd=w["Kfd"], depth_std=0.01, lindisp=w["lindisp"],
+                white_bkgd=w["white"], use_code_viewdirs=w["cv"], z_near=w["z"][0], z_far=w["z"][1], radius=w["radius"])
+    poses = np.stack([gu.pose_spherical(30.0 * v, -20.0, w["radius"]) for v in range(w["NS"])])[None]
+    net = build_net(spec, poses, device, precision)
+    rend = build_renderer(spec, device)
+    from pixel_nerf_multiscale_amd import util
+    tgt = util.pose_spherical(75.0, -25.0, w["radius"])[None].to(device)
+    rays = util.gen_rays(tgt, w["side"], w["side"], torch.tensor(w["focal"]), w["z"][0], w["z"][1]).reshape(1, -1, 8)
+    if rank_rays_scale > 1:
+        rays = rays.repeat(1, rank_rays_scale, 1)
+    return spec, net, rend, rays.contiguous()
+
+
+def cpu_baseline(spec, n_rays_sample, rays):
+    """The oracle restatement (port of the reference path, validated against reference fixtures) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    import golden_util as gu
+    from oracle import pixelnerf_oracle as orc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # a 1-GPU box's CPU share
+    W, H = spec["image"]
+    poses = np.stack([gu.pose_spherical(30.0 * v, -20.0, spec["radius"]) for v in range(spec["NS"])])[None]
+    cam = orc.encode_cameras(torch.from_numpy(poses), spec["focal"], None, W, H)
+    lat = [torch.from_numpy(x) for x in gu.make_latents(spec)]
+    sd_c = {k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, "coarse").items()}
+    sd_f = {k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, "fine").items()}
+    idx = torch.linspace(0, rays.shape[1] - 1, n_rays_sample).long()
+    r = rays[:, idx].cpu()
+    g = torch.Generator().manual_seed(0)
+    n_imp = spec["Kf"] - spec["Kfd"]
+    noise = dict(noise_c=torch.rand(n_rays_sample, spec["Kc"], generator=g), u=torch.rand(n_rays_sample, max(n_imp, 1), generator=g)[:, :n_imp],
+                 r=torch.rand(n_rays_sample, max(n_imp, 1), generator=g)[:, :n_imp], g=torch.randn(n_rays_sample, max(spec["Kfd"], 1), generator=g)[:, :spec["Kfd"]])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        res = orc.render(sd_c, sd_f, cam, lat, r, spec["NS"], spec["Kc"], spec["Kf"], spec["Kfd"], spec["depth_std"],
+                         spec["white_bkgd"], spec["lindisp"], noise, use_code_viewdirs=spec["use_code_viewdirs"])
+    dt = time.perf_counter() - t0
+    return n_rays_sample / dt, dt, res, idx, noise
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from pixel_nerf_multiscale_amd import _native as N
+    from pixel_nerf_multiscale_amd.parallel import ShardedRenderer
+    spec, net, rend, rays = build(args.workload, args.precision, device, rank_rays_scale=world)
+    R_total = rays.shape[1]                 # world x frame rays; each rank renders R_total / world of them
+    sharded = ShardedRenderer.for_model(rend, net, base_seed=1234)
+
+    # hipEvents around the dominant kernel, recorded by pnr_render on the stream it launches on
+    import ctypes as C
+    evs = []
+    for _ in range(2 * args.steps):
+        h = C.c_void_p()
+        N.check(N.lib.pnr_event_create(C.byref(h)), "pnr_event_create")
+        evs.append(h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sharded(rays)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rend.point_events = (evs[2 * i].value, evs[2 * i + 1].value)
+        rgb, depth = sharded(rays)
+    barrier()
+    dt = time.perf_counter() - t0
+    rend.point_events = None
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel (fused point network of the coarse pass): average launch duration over the timed region
+    kms = []
+    for i in range(args.steps):
+        ms = C.c_float()
+        N.check(N.lib.pnr_event_elapsed_ms(evs[2 * i], evs[2 * i + 1], C.byref(ms)), "pnr_event_elapsed_ms")
+        kms.append(ms.value)
+    for h in evs:
+        N.lib.pnr_event_destroy(h)
+    k_ms = float(np.mean(kms))
+    rays_per_rank = R_total // world
+    fpp = flops_per_point(spec["NS"], sum(c for c, _, _ in spec["lat"]), net.d_in)
+    flops_launch = rays_per_rank * spec["Kc"] * fpp
+    achieved = flops_launch / (k_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+
+    out = {
+        "metric": "rendered rays/sec (128 samples/ray), SRN chairs 1-view",
+        "value": R_total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": args.workload, "rays_per_step": R_total, "rays_per_gpu": rays_per_rank,
+                   "samples_per_ray": spec["Kc"] + spec["Kf"], "n_coarse": spec["Kc"], "n_fine": spec["Kf"],
+                   "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
+        "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "kernel_ms": k_ms, "flops_per_launch": flops_launch},
+    }
+    if rank == 0 and world == 1 and args.cpu_rays > 0:
+        v, cdt, res, idx, noise = cpu_baseline(spec, args.cpu_rays, rays)
+        out["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{args.cpu_rays} rays of the same frame, {spec['Kc']}+{spec['Kf']} samples/ray, oracle/pixelnerf_oracle.py (PyTorch-CPU fp32), {cdt:.1f} s"}
+        # PSNR-equivalent of the GPU path vs the CPU oracle on the sample, identical noise
+        rend.fixed_noise = {k: t.to(device) for k, t in noise.items() if t.numel() > 0}
+        o = rend(net, rays[:, idx.to(device)].contiguous())
+        rend.fixed_noise = None
+        lvl = "fine" if spec["Kf"] > 0 else "coarse"
+        mse = float(((o[lvl].rgb.cpu() - res[lvl]["rgb"]) ** 2).mean())
+        out["psnr_vs_oracle_db"] = 99.0 if mse == 0 else -10 * math.log10(mse)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

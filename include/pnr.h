@@ -122,6 +122,10 @@ typedef struct pnr_outputs {
     float* fine_weights;         /* (N,Kc+Kf) */
     float* z_coarse;             /* (N,Kc)    sampled depths (debug / tests) */
     float* z_fine;               /* (N,Kc+Kf) sorted */
+    /* optional hipEvent_t handles recorded on `stream` immediately before / after the COARSE pass's point-network
+     * launch (the dominant kernel), so a caller can time that kernel inside a whole-path call; NULL = off */
+    void* ev_point_begin;
+    void* ev_point_end;
 } pnr_outputs;
 
 int32_t pnr_version(void);

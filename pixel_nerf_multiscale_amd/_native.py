@@ -58,7 +58,8 @@ class pnr_noise(C.Structure):
 
 class pnr_outputs(C.Structure):
     _fields_ = [("coarse_rgb", _fp), ("coarse_depth", _fp), ("coarse_weights", _fp), ("fine_rgb", _fp),
-                ("fine_depth", _fp), ("fine_weights", _fp), ("z_coarse", _fp), ("z_fine", _fp)]
+                ("fine_depth", _fp), ("fine_weights", _fp), ("z_coarse", _fp), ("z_fine", _fp),
+                ("ev_point_begin", _fp), ("ev_point_end", _fp)]
 
 
 # every symbol include/pnr.h declares: name -> (restype, argtypes)

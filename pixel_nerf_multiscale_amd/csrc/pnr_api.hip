@@ -149,7 +149,9 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     // coarse pass (nerf.py:273-282)
     if ((rc = pnr_sample_coarse(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, ray_index_base, zc, stream))) return rc;
     PointSrc src{rays, zc, Kc, nullptr, nullptr};
+    if (outputs->ev_point_begin) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_begin, s));
     if ((rc = point_dispatch(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s))) return rc;
+    if (outputs->ev_point_end) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_end, s));
     if ((rc = pnr_composite(rays, zc, rgbs, n_rays, Kc, params->white_bkgd, w_c, rgb_c, dep_c, stream))) return rc;
     if (Kf == 0) return PNR_OK;
 

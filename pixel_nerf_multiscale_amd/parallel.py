@@ -1,0 +1,78 @@
+"""
+Multi-GPU rendering: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), replacing the
+reference's single-process nn.DataParallel(dim=1) (reference render/nerf.py:367-371, broken there: SURVEY D8).
+
+Rays are independent units, so a frame is cut into contiguous ray ranges, one per rank; every rank holds the
+same packed weights and latents (loaded / encoded locally), renders its range with the in-kernel noise keyed
+by the GLOBAL ray index, and ONE collective per frame — an all_gather of (rays/world, 4) fp32 [rgb, depth] —
+reassembles the pixels on every rank.  With the same seed the gathered frame is bit-identical to the 1-GPU frame.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, world, rank):
+    """Contiguous [lo, hi) of rank's rays; every rank gets ceil(n/world) except the tail."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n), per
+
+
+def frame_seed(base_seed, frame_idx):
+    """Per-frame kernel seed derived without communication (splitmix64 step)."""
+    z = (int(base_seed) + 0x9E3779B97F4A7C15 * (int(frame_idx) + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
+
+
+class ShardedRenderer:
+    """render_shard(rays (1, n, 8), ray_index_base, seed) -> (rgb (1,n,3), depth (1,n)) is the per-rank renderer;
+    __call__(rays (1, B, 8)) returns the full (rgb (1,B,3), depth (1,B)) on every rank."""
+
+    def __init__(self, render_shard, group=None, base_seed=None):
+        self.render_shard = render_shard
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.frame_idx = 0
+        if base_seed is None:
+            t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+            if self.world > 1:
+                dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+                t = t.to(dev)
+                dist.broadcast(t, src=0, group=group)      # once, at construction
+            base_seed = int(t.item())
+        self.base_seed = base_seed
+
+    @classmethod
+    def for_model(cls, renderer, net, **kw):
+        """Bind a NeRFRenderer + PixelNeRFNet (simple_output semantics: fine if using_fine else coarse)."""
+        def render_shard(rays, base, seed):
+            renderer.ray_index_base, renderer.forced_seed = base, seed
+            try:
+                out = renderer(net, rays)
+            finally:
+                renderer.ray_index_base, renderer.forced_seed = 0, None
+            lvl = out.fine if renderer.using_fine else out.coarse
+            return lvl.rgb, lvl.depth
+        return cls(render_shard, **kw)
+
+    def __call__(self, rays):
+        assert rays.dim() == 3 and rays.shape[0] == 1, "sharded rendering takes one object per call: rays (1, B, 8)"
+        B = rays.shape[1]
+        lo, hi, per = shard_range(B, self.world, self.rank)
+        seed = frame_seed(self.base_seed, self.frame_idx)
+        self.frame_idx += 1
+        pix = torch.zeros(per, 4, device=rays.device, dtype=torch.float32)
+        if hi > lo:
+            rgb, depth = self.render_shard(rays[:, lo:hi].contiguous(), lo, seed)
+            pix[: hi - lo, :3] = rgb.reshape(-1, 3)
+            pix[: hi - lo, 3] = depth.reshape(-1)
+        if self.world > 1:
+            full = torch.empty(self.world * per, 4, device=rays.device, dtype=torch.float32)
+            dist.all_gather_into_tensor(full, pix, group=self.group)
+        else:
+            full = pix
+        full = full[:B]
+        return full[:, :3].reshape(1, B, 3), full[:, 3].reshape(1, B)

@@ -51,6 +51,7 @@ class NeRFRenderer(torch.nn.Module):
         self.fixed_noise = None
         self.ray_index_base = 0      # global index of rays[0] when a frame is sharded over ranks
         self.last_seed = None
+        self.forced_seed = None      # explicit kernel seed (ShardedRenderer: same seed on every rank)
         self._ws = None
 
     # ------------------------------------------------------------------ stage wrappers (reference method names)
@@ -66,7 +67,7 @@ class NeRFRenderer(torch.nn.Module):
         return nz, keep
 
     def _seed(self):
-        self.last_seed = seed_from_torch()
+        self.last_seed = seed_from_torch() if self.forced_seed is None else int(self.forced_seed)
         return self.last_seed
 
     def sample_coarse(self, rays, seed=None):
@@ -175,6 +176,8 @@ class NeRFRenderer(torch.nn.Module):
             if Kf > 0:
                 res.fine.z = torch.empty(SB, B, Kc + Kf, device=dev)
                 o.z_fine = N.ptr(res.fine.z)
+        if getattr(self, "point_events", None) is not None:      # (begin, end) native event handles, see bench.py
+            o.ev_point_begin, o.ev_point_end = self.point_events
         nz, k4 = self._noise_ptrs(dev)
         nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mc), C.byref(v), n)
         ws = net.workspace(nbytes, dev)

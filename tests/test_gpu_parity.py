@@ -181,3 +181,84 @@ def test_empty_and_error_paths():
         rend(net, torch.from_numpy(fx["rays"]))           # CPU rays: no CPU path
     with pytest.raises(ValueError):
         rend(net, torch.zeros(3, 4, 8, device="cuda"))    # 3 objects vs 1 encoded
+
+
+# ----------------------------------------------------------------------------- fused MFMA path (bf16 / fp16)
+FULL = [n for n in ALL if n.startswith("full")]
+
+
+def _psnr(a, b):
+    mse = float(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean())
+    return 99.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+# Low-precision tolerance: the reference has no bf16/fp16 numerics; the bound is PSNR(build, fp32
+# reference) on the rendered pixels — the north-star's 0.05 dB budget is >= 42.4 dB for uncorrelated error; the
+# 16-ray fixtures are small samples, so the per-fixture floors sit a little below the 50 dB frame-level floor that
+# test_mfma_frame_psnr enforces on 4096 rays.
+@pytest.mark.parametrize("prec,floor_pts,floor_px", [("bf16", 52.0, 46.0), ("fp16", 68.0, 62.0)])
+@pytest.mark.parametrize("name", FULL)
+def test_mfma_matches_reference(name, prec, floor_pts, floor_px):
+    from hip_util import setup
+    fx, spec, net, rend = setup(name, precision=prec)
+    assert net.resolved_precision() == prec
+    for tag in ("coarse", "fine"):
+        out = net(_dev(fx[f"pts_xyz_{tag}"]), coarse=(tag == "coarse"), viewdirs=_dev(fx[f"pts_dirs_{tag}"])).cpu().numpy()
+        ref = fx[f"pts_out_{tag}"]
+        assert not np.isnan(out).any()
+        assert _psnr(out[..., :3], ref[..., :3]) >= floor_pts, tag
+        rel = np.abs(out[..., 3] - ref[..., 3]) / (1.0 + np.abs(ref[..., 3]))
+        assert rel.max() <= (0.25 if prec == "bf16" else 0.05), tag          # sigma logits are x20 in the fixtures
+    out = rend(net, _dev(fx["rays"]), want_weights=True)
+    for lvl in ("coarse", "fine"):
+        assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= floor_px, lvl
+        assert maxdiff(out[lvl].weights.cpu(), fx[f"{lvl}_weights"]) <= (0.05 if prec == "bf16" else 0.01), lvl
+
+
+@pytest.mark.parametrize("prec,floor", [("bf16", 50.0), ("fp16", 65.0)])
+def test_mfma_frame_psnr(prec, floor):
+    """4096 rays x 64 coarse samples, NS=1: MFMA path vs the fp32 HIP path (itself pinned to the reference at
+    1e-4) with identical in-kernel noise.  Also exercises the tail tile and a ray count that is not a tile multiple."""
+    from hip_util import build_net, build_renderer
+    import golden_util as gu
+    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=64, Kf=0, Kfd=0)
+    poses = np.stack([gu.pose_spherical(0.0, -20.0, spec["radius"])])[None]
+    g = torch.Generator().manual_seed(1)
+    W, H = spec["image"]
+    tgt = gu.pose_spherical(75.0, -25.0, spec["radius"])
+    rays = torch.from_numpy(gu.pinhole_rays(tgt, W, H, spec["focal"], spec["z_near"], spec["z_far"],
+                                            torch.randperm(W * H, generator=g)[:4093].numpy()))[None].cuda()
+    outs = {}
+    for p in ("fp32", prec):
+        net = build_net(spec, poses, "cuda", p)
+        rend = build_renderer(spec)
+        rend.forced_seed = 99
+        outs[p] = rend(net, rays).coarse.rgb.cpu()
+    assert _psnr(outs[prec], outs["fp32"]) >= floor
+
+
+def test_mfma_multiview_large():
+    """NS=3 (view spill/reduce path) on enough points that every workgroup loops over several tiles."""
+    from hip_util import build_net
+    import golden_util as gu
+    spec = dict(gu.CASES["full_ns3"])
+    fx = gu.load_fixture("full_ns3")
+    g = torch.Generator().manual_seed(2)
+    xyz = ((torch.rand(1, 40000, 3, generator=g) - 0.5) * 1.6).cuda()
+    vd = torch.nn.functional.normalize(torch.randn(1, 40000, 3, generator=g), dim=-1).cuda()
+    ref = build_net(spec, fx["poses"], "cuda", "fp32")(xyz, viewdirs=vd).cpu().numpy()
+    out = build_net(spec, fx["poses"], "cuda", "fp16")(xyz, viewdirs=vd).cpu().numpy()
+    assert _psnr(out[..., :3], ref[..., :3]) >= 65.0
+    out = build_net(spec, fx["poses"], "cuda", "bf16")(xyz, viewdirs=vd).cpu().numpy()
+    assert _psnr(out[..., :3], ref[..., :3]) >= 50.0
+
+
+def test_mfma_requires_packed_and_supported_shape():
+    """The low-precision path fails loudly (no fallback) on shapes the fused kernel is not built for."""
+    from hip_util import setup
+    fx, spec, net, rend = setup("tiny_ns1", precision="bf16")
+    with pytest.raises(ValueError):
+        rend(net, _dev(fx["rays"]))
+    net.precision = "auto"                      # auto -> fp32 HIP path for d_hidden=32
+    assert net.resolved_precision() == "fp32"
+    rend(net, _dev(fx["rays"]))
