@@ -9,7 +9,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpnr_hip.so")
+LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(HERE, "lib", "libpnr_hip.so")   # PNR_LIB: diagnostic builds (tools/dev)
 
 PNR_MAX_LEVELS = 5
 PNR_MAX_BLOCKS = 8

@@ -32,8 +32,7 @@ typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // one 16-bit x8 
 static constexpr int HID = 512;          // d_hidden the kernel is specialised for
 static constexpr int NT = HID / 32;      // 16 feature tiles of 32 rows
 static constexpr int STAGE_BYTES = 16384;
-static constexpr int RING_SLOTS = 5;     // >= PREFETCH + 3 (one published stage is read ahead into registers)
-static constexpr int PREFETCH = 2;       // stages in flight beyond the one being consumed
+static constexpr int RING_SLOTS = 5;     // stage i+4 is loaded while stage i is consumed and stage i+1 read ahead
 static constexpr int TILE_PTS = 128;
 static constexpr int ZBUF_BYTES = 16384; // per wave: 16 k-steps x 64 lanes x 16 B (256 latent channels)
 static constexpr int LDS_RING = 0;
@@ -52,6 +51,14 @@ template <> struct Num<PNR_BF16> {
     static __device__ __forceinline__ uint16_t one() { return 0x3F80; }
     static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
     static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
+    // relu(pack(a0, a1)) straight from two accumulator (AGPR) registers, as ONE asm statement: hipcc cannot pull the
+    // reads ahead of the conversion (which made it spill whole tiles to scratch around the snapshot)
+    static __device__ __forceinline__ uint32_t snap2(float a0, float a1) {
+        uint32_t out, tmp;
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_bf16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0"
+                     : "=&v"(out), "=&v"(tmp) : "a"(a0), "a"(a1));
+        return out;
+    }
     static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -66,6 +73,12 @@ template <> struct Num<PNR_F16> {
     static __device__ __forceinline__ uint16_t one() { return 0x3C00; }
     static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
     static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
+    static __device__ __forceinline__ uint32_t snap2(float a0, float a1) {
+        uint32_t out, tmp;
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0"
+                     : "=&v"(out), "=&v"(tmp) : "a"(a0), "a"(a1));
+        return out;
+    }
     static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
@@ -230,26 +243,37 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
-// 4 x 1 KiB LDS-DMA (global_load_lds_dwordx4) of one wave's quarter of a stage: lane l moves 16 B from
-// g + 1024 q + 16 l to LDS dst + 1024 q + 16 l.  Inline asm so that hipcc neither counts these loads in its own
-// vmcnt bookkeeping nor drains them before barriers / ds_reads; they are retired by the counted s_waitcnt in
-// begin_stage (cdna_hip_programming.md §5.7).  The instruction offset applies to both addresses.
-__device__ __forceinline__ void glds_quarter(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
+// One 1 KiB LDS-DMA piece (global_load_lds_dwordx4): lane l moves 16 B from g_base + lane_off to LDS lds_dst + 16 l.
+// Inline asm so that hipcc neither counts these loads in its own vmcnt bookkeeping nor drains them before
+// barriers / ds_reads; they are retired by the counted s_waitcnt in begin_stage (cdna_hip_programming.md §5.7).
+// A piece costs ~60 issue cycles, so the 4 pieces a wave owes per stage are spread between the stage's MFMAs.
+__device__ __forceinline__ void glds_piece(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
+// Diagnostic build only (-DPNR_STAMPS): per-section shader-cycle sums, never part of the product library.
+#ifdef PNR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_ACC(idx, t0v) do { unsigned long long _t; STAMP(_t); st_acc[idx] += _t - (t0v); (t0v) = _t; } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#define STAMP_ACC(idx, t0v) do { } while (0)
+#endif
+
 template <int DT, bool MULTIVIEW>
 __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
+#ifdef PNR_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = 0, st_tile = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Num<DT> NM;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -263,27 +287,33 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
     const uint32_t gl_off = (uint32_t)(wv * 4096 + lane * 16);
     const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
-    auto issue_stage = [&]() {
-        glds_quarter(a.stream + (size_t)ld_idx * STAGE_BYTES, gl_off,
-                     __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES));
-        ld_slot = (ld_slot + 1 == RING_SLOTS) ? 0 : ld_slot + 1;
-        ++ld_idx;
-        if (ld_rep < a.NS) {
-            if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
-        } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
+    // piece q (0..3) of the loader's current stage; the cursor advances after the 4th piece
+    auto issue_piece = [&](int q) {
+#ifndef PNR_X_NODMA          // timing experiment only: no weight DMA (results are garbage)
+        glds_piece(a.stream + (size_t)ld_idx * STAGE_BYTES + q * 1024, gl_off,
+                   __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES + q * 1024));
+#endif
+        if (q == 3) {
+            ld_slot = (ld_slot + 1 == RING_SLOTS) ? 0 : ld_slot + 1;
+            ++ld_idx;
+            if (ld_rep < a.NS) {
+                if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
+            } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
+        }
     };
-    // Stage protocol.  On entry to stage i its fragments are already PUBLISHED (all waves' DMA landed + a barrier
-    // passed) and its first 8 fragments sit in registers A[0..7].  begin_stage(): start the DMA of stage
-    // i+PREFETCH+1, wait until this wave's DMA of stage i+1 has landed, barrier => stage i+1 is published and
-    // may be read (prefetched into A) during stage i.  A slot is rewritten RING_SLOTS stages later; the readers of
-    // its previous content (stage i-2 and older) have all passed two barriers since.  RING_SLOTS >= PREFETCH + 3.
+    // Stage protocol.  On entry to stage i its fragments are PUBLISHED (all waves' DMA landed + a barrier passed)
+    // and its first 8 fragments sit in registers A[0..7].  begin_stage(): wait until this wave's DMA of stage i+1
+    // has landed (the 8 younger pieces = stages i+2, i+3 may stay in flight), barrier => stage i+1 is published and
+    // may be read ahead into A during stage i.  During stage i every wave issues its 4 pieces of stage i+4, one after
+    // MFMAs 1, 5, 9, 13 (PNR_DMA).  That slot held stage i-1, whose last readers passed the barrier of stage i.
     frag_t A[8];
     const char* cur;    // this lane's read base of the stage being consumed
     const char* nxt;    // ... of the next stage
     auto begin_stage = [&]() {
-        issue_stage();
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // 4 x PREFETCH younger loads may stay in flight
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef PNR_X_NOBARRIER      // timing experiment only
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         cur = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
         st_slot = (st_slot + 1 == RING_SLOTS) ? 0 : st_slot + 1;
@@ -291,10 +321,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
     // fragment f of the current stage is in A[f & 7]; after using it, refill the register 8 fragments ahead
 #define PNR_REFILL(f) A[(f) & 7] = *(const frag_t*)(((f) < 8 ? cur : nxt) + (((f) + 8) & 15) * 1024)
+#define PNR_DMA(f) if (((f) & 3) == 1) issue_piece((f) >> 2)
 
 #pragma unroll
-    for (int i = 0; i < PREFETCH + 1; ++i) issue_stage();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int i = 0; i < RING_SLOTS - 1; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(q);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // stage 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -311,7 +344,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
             x[f] = NM::mfma(A[f & 7], B, x[f]);
-            PNR_REFILL(f);
+            PNR_REFILL(f); PNR_DMA(f);
         }
     };
     // n_lds k-steps whose B fragment is image [k-step][lane] in this wave's LDS buffer, then n_bias bias stages
@@ -324,22 +357,22 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             Bz = Bn;
         }
     };
+    // relu(X^T) -> 16-bit B fragments (see Num::snap2)
     auto snapshot = [&]() {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMA's accumulator writes have retired
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 frag_t v;
-                v.x = relu_pk(NM::pack(x[t][8 * s + 0], x[t][8 * s + 1]));
-                v.y = relu_pk(NM::pack(x[t][8 * s + 2], x[t][8 * s + 3]));
-                v.z = relu_pk(NM::pack(x[t][8 * s + 4], x[t][8 * s + 5]));
-                v.w = relu_pk(NM::pack(x[t][8 * s + 6], x[t][8 * s + 7]));
+                v.x = NM::snap2(x[t][8 * s + 0], x[t][8 * s + 1]);
+                v.y = NM::snap2(x[t][8 * s + 2], x[t][8 * s + 3]);
+                v.z = NM::snap2(x[t][8 * s + 4], x[t][8 * s + 5]);
+                v.w = NM::snap2(x[t][8 * s + 6], x[t][8 * s + 7]);
                 xb[t][s] = v;
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // one 32-row chunk of a [.. x 512] product against xb: acc = W[chunk rows] . relu(X)   (2 stages)
     // hipcc gives every MFMA of a kernel that needs AGPRs the AGPR form, and all 256 AGPRs hold X^T: for this chain it
     // parks one X^T tile in VGPRs (v_accvgpr_read/write, hidden under the MFMAs).  A VGPR-form inline-asm chain was
     // tried and is wrong by construction: the register allocator may put v_mov copies of the accumulator between two
@@ -351,7 +384,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
                 acc = NM::mfma(A[f & 7], xb[8 * half + (f >> 1)][f & 1], acc);
-                PNR_REFILL(f);
+                PNR_REFILL(f); PNR_DMA(f);
             }
         }
         return acc;
@@ -369,6 +402,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 
     const int n_groups = a.SZ / 16;               // latent channel groups of 256 (the LDS image holds one)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        STAMP(st_t);
+#ifdef PNR_STAMPS
+        st_tile = st_t;
+#endif
         const int64_t g = (int64_t)tile * TILE_PTS + wv * 32 + r;
         const bool live = g < a.n_points;
         const int64_t gc = live ? g : a.n_points - 1;
@@ -447,6 +484,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     }
                     if (h == 0) { put(a.d_in, 1.0f); put(a.d_in + 1, 1.0f); }     // folded lin_in bias (hi, lo)
                 }
+                STAMP_ACC(1, st_t);
                 // ---- LIN_IN: x = W_in . features
                 {
                     f32x16 zero;
@@ -457,6 +495,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 }
                 x_stages(a.S_in, 0);
                 if (n_groups == 1) gather(0);
+                STAMP_ACC(2, st_t);
             }
             // ---- x += lin_z[b](z)  (blocks before the view reduction only)
             if (b < a.nb1) {
@@ -465,9 +504,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     x_stages(16, grp == n_groups - 1 ? 1 : 0);       // last group: + lin_z.bias
                 }
             }
+            STAMP_ACC(3, st_t);
             // ---- resblock: x += fc_1(relu(fc_0(relu(x)))) + biases  (resnetfc.py:53-62)
             snapshot();
+            STAMP_ACC(4, st_t);
             x_stages(0, 1);                       // + fc_1.bias
+            STAMP_ACC(5, st_t);
             {
                 f32x16 hacc = load_hbias(b, 0);
 #pragma unroll 1
@@ -489,11 +531,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         for (int f = 0; f < 16; ++f) {
                             const int tn = 8 * half + (f >> 1);
                             x[tn] = NM::mfma(A[f & 7], hb[f & 1], x[tn]);
-                            PNR_REFILL(f);
+                            PNR_REFILL(f); PNR_DMA(f);
                         }
                     }
                 }
             }
+            STAMP_ACC(6, st_t);
             ++b;
             // ---- multi-view reduction after the last per-view block (util.combine_interleaved, util.py:466-476)
             if (MULTIVIEW && b == a.nb1 && a.NS > 1) {
@@ -556,11 +599,20 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             res.w = fmaxf(o[3], 0.f);
             ((float4*)a.out)[g] = res;
         }
+        STAMP_ACC(7, st_t);
+#ifdef PNR_STAMPS
+        st_acc[0] += st_t - st_tile;
+#endif
     }
+#ifdef PNR_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead LDS-DMA before the LDS is released
     asm volatile("" :: "v"(A[0].x), "v"(A[1].x), "v"(A[2].x), "v"(A[3].x), "v"(A[4].x), "v"(A[5].x), "v"(A[6].x), "v"(A[7].x));
 }
 #undef PNR_REFILL
+#undef PNR_DMA
 
 // ---------------------------------------------------------------------------- host side
 static int num_cus() {
@@ -625,6 +677,18 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
 }  // namespace pnr
 
 using namespace pnr;
+
+#ifdef PNR_STAMPS
+extern "C" int32_t pnr_debug_stamps(unsigned long long* out16, int reset) {
+    PNR_HIP_CHECK(hipDeviceSynchronize());
+    PNR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pnr::g_stamps), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        PNR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_stamps), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
 
 extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
     Layout y;

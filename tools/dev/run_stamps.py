@@ -1,0 +1,25 @@
+"""Diagnostic (GPU box): section shares of the fused kernel from the -DPNR_STAMPS build."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PNR_LIB", os.path.join(ROOT, "tools", "dev", "libpnr_stamps.so"))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch
+import bench
+from pixel_nerf_multiscale_amd import _native as N
+wl = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
+spec, net, rend, rays = bench.build(wl, "bf16", torch.device("cuda"))
+fn = N.lib.pnr_debug_stamps
+fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * 16)()
+for _ in range(2): rend(net, rays)
+fn(buf, 1)
+for _ in range(3): rend(net, rays)
+fn(buf, 1)
+import time
+torch.cuda.synchronize(); t0=time.perf_counter()
+for _ in range(5): rend(net, rays)
+torch.cuda.synchronize(); print("ms/frame (stamped build)", (time.perf_counter()-t0)/5*1e3)
+names = ["tile total", "prologue(geom+posenc)", "lin_in+gather", "lin_z", "snapshot", "bias stage", "chunk loop", "lin_out+store"]
+tot = buf[0]
+for i, n in enumerate(names):
+    print(f"{n:24s} {buf[i]/tot*100:6.2f}%   cycles/wave/tile = {buf[i]/ (3*1024*64):10.0f}")

@@ -1,0 +1,20 @@
+#!/bin/bash
+# PMC passes of the headline bench (GPU box).  Separate runs per counter group (SQ 8 slots, TCC 4 slots; FETCH_SIZE=3, WRITE_SIZE=2).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_${1:-r01}
+ARGS="--steps 3 --warmup 1 --cpu-rays 0 ${@:2}"
+rocprofv3 --kernel-trace --output-format csv -d $OUT/p1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py $ARGS > $OUT.p1.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/p2 --pmc FETCH_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES -- python bench.py $ARGS > $OUT.p2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/p3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python bench.py $ARGS > $OUT.p3.log 2>&1
+python - <<PY
+import csv, glob, collections
+for p in ("p1","p2","p3"):
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True):
+        acc = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "k_point_mfma" in row["Kernel_Name"]:
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            print(p, k, "n=%d mean=%.6g" % (len(v), sum(v)/len(v)))
+PY
