@@ -148,3 +148,19 @@ def seed_from_torch():
     torch.manual_seed like the reference's torch.rand calls do."""
     hi, lo = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
     return (hi << 31) | lo
+
+
+def gen_rays_device(pose, width, height, focal, z_near, z_far, c=None, device="cuda"):
+    """gen_rays for ONE camera, computed on the GPU by libpnr_hip (pnr_gen_rays): pose (4,4) c2w on the host ->
+    rays (H*W, 8) on `device`, never materialised on the host."""
+    import ctypes as C
+    from . import _native as N
+    f = torch.as_tensor(focal, dtype=torch.float32).flatten()
+    fx, fy = float(f[0]), float(f[-1])
+    cx, cy = (width * 0.5, height * 0.5) if c is None else (float(torch.as_tensor(c).flatten()[0]), float(torch.as_tensor(c).flatten()[1]))
+    dev = torch.device(device)
+    out = torch.empty(width * height, 8, device=dev, dtype=torch.float32)
+    m = (C.c_float * 16)(*[float(v) for v in torch.as_tensor(pose, dtype=torch.float32).cpu().flatten().tolist()])
+    N.check(N.lib.pnr_gen_rays(m, int(width), int(height), fx, fy, cx, cy, float(z_near), float(z_far), 0,
+                               width * height, N.ptr(out), N.current_stream(dev)), "pnr_gen_rays")
+    return out

@@ -262,3 +262,16 @@ def test_mfma_requires_packed_and_supported_shape():
     net.precision = "auto"                      # auto -> fp32 HIP path for d_hidden=32
     assert net.resolved_precision() == "fp32"
     rend(net, _dev(fx["rays"]))
+
+
+def test_gen_rays_kernel_matches_host():
+    """N1: on-device ray generation == the host gen_rays mirror == the fixtures' pinhole model."""
+    from pixel_nerf_multiscale_amd import util
+    import golden_util as gu
+    pose = util.pose_spherical(75.0, -25.0, 2.0)
+    W, H, f = 40, 30, 45.0
+    dev = util.gen_rays_device(pose, W, H, f, 1.25, 2.75).cpu()
+    host = util.gen_rays(pose[None], W, H, torch.tensor(f), 1.25, 2.75).reshape(-1, 8)
+    assert maxdiff(dev, host) <= 2e-6
+    ref = gu.pinhole_rays(gu.pose_spherical(75.0, -25.0, 2.0), W, H, f, 1.25, 2.75, np.arange(W * H))
+    assert maxdiff(dev, ref) <= 2e-6
