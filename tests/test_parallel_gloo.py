@@ -31,7 +31,7 @@ def _worker(rank, world, port, B, q):
         rays = torch.rand(1, B, 8, generator=g)
         sr = ShardedRenderer(fake_render)                  # base seed broadcast from rank 0
         outs = [sr(rays) for _ in range(2)]                # two frames: different per-frame seeds
-        q.put((rank, sr.base_seed, [(r.clone(), d.clone()) for r, d in outs]))
+        q.put((rank, sr.base_seed, [(r.numpy().copy(), d.numpy().copy()) for r, d in outs]))   # by value, not shared storage
     finally:
         dist.destroy_process_group()
 
@@ -64,7 +64,7 @@ def test_sharded_equals_unsharded(world, B):
     for frame in range(2):
         ref_rgb, ref_depth = fake_render(rays, 0, frame_seed(base, frame))
         for rank, _, outs in res:
-            rgb, depth = outs[frame]
+            rgb, depth = (torch.from_numpy(t) for t in outs[frame])
             assert rgb.shape == (1, B, 3) and depth.shape == (1, B)
             assert torch.equal(rgb, ref_rgb) and torch.equal(depth, ref_depth), (rank, frame)
 
