@@ -16,6 +16,8 @@
 //     latent copy and writes the interpolated channels straight into the wave's LDS B-fragment image.
 //   * multi-view: the first `combine_layer` blocks run once per source view on the same 128 points; the per-view
 //     residual streams are parked in a caller-provided workspace and reduced (mean/max) in registers.
+#include <type_traits>
+
 #include "pnr_common.h"
 
 namespace pnr {
@@ -243,19 +245,19 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
-// One 1 KiB LDS-DMA piece (global_load_lds_dwordx4): lane l moves 16 B from g_base + lane_off to LDS lds_dst + 16 l.
-// Inline asm so that hipcc neither counts these loads in its own vmcnt bookkeeping nor drains them before
-// barriers / ds_reads; they are retired by the counted s_waitcnt in begin_stage (cdna_hip_programming.md §5.7).
-// A piece costs ~60 issue cycles, so the 4 pieces a wave owes per stage are spread between the stage's MFMAs.
+// One 1 KiB LDS-DMA piece (global_load_lds_dwordx4): lane l moves 16 B from g_base + lane_off + 1024 Q to LDS
+// lds_dst + 1024 Q + 16 l (the instruction offset applies to both addresses).  Inline asm so that hipcc neither counts
+// these loads in its own vmcnt bookkeeping nor drains them before barriers / ds_reads; they are retired by the counted
+// s_waitcnt in begin_stage (cdna_hip_programming.md §5.7).  A piece costs the wave ~16 issue cycles plus ~4 per scalar
+// instruction around it, so: M0 is (re)written in the same statement but not saved/restored (nothing else in this
+// kernel uses M0 — build_native.py checks the ISA), the per-piece addresses come from the immediate offset, and the 4
+// pieces a wave owes per stage are spread between the stage's MFMAs.
+template <int Q>
 __device__ __forceinline__ void glds_piece(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
 // Diagnostic build only (-DPNR_STAMPS): per-section shader-cycle sums, never part of the product library.
@@ -271,7 +273,7 @@ __device__ unsigned long long g_stamps[16];
 template <int DT, bool MULTIVIEW>
 __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #ifdef PNR_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = 0, st_tile = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -287,18 +289,28 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
     const uint32_t gl_off = (uint32_t)(wv * 4096 + lane * 16);
     const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
-    // piece q (0..3) of the loader's current stage; the cursor advances after the 4th piece
-    auto issue_piece = [&](int q) {
-#ifndef PNR_X_NODMA          // timing experiment only: no weight DMA (results are garbage)
-        glds_piece(a.stream + (size_t)ld_idx * STAGE_BYTES + q * 1024, gl_off,
-                   __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES + q * 1024));
+    // piece Q (0..3) of the loader's current stage; the cursor advances after the 4th piece
+    const char* dma_g = a.stream;                               // global base of the stage being loaded (uniform)
+    uint32_t dma_l = __builtin_amdgcn_readfirstlane(ring_lds);  // LDS base of its slot (+ this wave's quarter)
+    auto issue_piece = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+#ifdef PNR_STAMPS_FINE
+        unsigned long long _ti; STAMP(_ti);
 #endif
-        if (q == 3) {
+#ifndef PNR_X_NODMA          // timing experiment only: no weight DMA (results are garbage)
+        glds_piece<Q>(dma_g, gl_off, dma_l);
+#endif
+#ifdef PNR_STAMPS_FINE
+        { unsigned long long _t2; STAMP(_t2); st_acc[9] += _t2 - _ti; }
+#endif
+        if (Q == 3) {
             ld_slot = (ld_slot + 1 == RING_SLOTS) ? 0 : ld_slot + 1;
             ++ld_idx;
             if (ld_rep < a.NS) {
                 if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
             } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
+            dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
+            dma_l = __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES);
         }
     };
     // Stage protocol.  On entry to stage i its fragments are PUBLISHED (all waves' DMA landed + a barrier passed)
@@ -310,9 +322,17 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     const char* cur;    // this lane's read base of the stage being consumed
     const char* nxt;    // ... of the next stage
     auto begin_stage = [&]() {
+#ifdef PNR_STAMPS_FINE
+        unsigned long long _tb; STAMP(_tb);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        { unsigned long long _t2; STAMP(_t2); st_acc[8] += _t2 - _tb; _tb = _t2; }
+        __builtin_amdgcn_s_barrier();
+        { unsigned long long _t2; STAMP(_t2); st_acc[10] += _t2 - _tb; }
+#else
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #ifndef PNR_X_NOBARRIER      // timing experiment only
         __builtin_amdgcn_s_barrier();
+#endif
 #endif
         asm volatile("" ::: "memory");
         cur = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
@@ -321,12 +341,18 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
     // fragment f of the current stage is in A[f & 7]; after using it, refill the register 8 fragments ahead
 #define PNR_REFILL(f) A[(f) & 7] = *(const frag_t*)(((f) < 8 ? cur : nxt) + (((f) + 8) & 15) * 1024)
-#define PNR_DMA(f) if (((f) & 3) == 1) issue_piece((f) >> 2)
+#define PNR_DMA(f) do { if ((f) == 1) issue_piece(std::integral_constant<int, 0>{}); else if ((f) == 5) issue_piece(std::integral_constant<int, 1>{}); \
+                        else if ((f) == 9) issue_piece(std::integral_constant<int, 2>{}); else if ((f) == 13) issue_piece(std::integral_constant<int, 3>{}); } while (0)
 
 #pragma unroll
     for (int i = 0; i < RING_SLOTS - 1; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_piece(q);
+        for (int q = 0; q < 4; ++q) {
+            if (q == 0) issue_piece(std::integral_constant<int, 0>{});
+            if (q == 1) issue_piece(std::integral_constant<int, 1>{});
+            if (q == 2) issue_piece(std::integral_constant<int, 2>{});
+            if (q == 3) issue_piece(std::integral_constant<int, 3>{});
+        }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // stage 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -606,7 +632,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     }
 #ifdef PNR_STAMPS
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead LDS-DMA before the LDS is released
     asm volatile("" :: "v"(A[0].x), "v"(A[1].x), "v"(A[2].x), "v"(A[3].x), "v"(A[4].x), "v"(A[5].x), "v"(A[6].x), "v"(A[7].x));
