@@ -34,7 +34,7 @@ typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // one 16-bit x8 
 static constexpr int HID = 512;          // d_hidden the kernel is specialised for
 static constexpr int NT = HID / 32;      // 16 feature tiles of 32 rows
 static constexpr int STAGE_BYTES = 16384;
-static constexpr int RING_SLOTS = 5;     // stage i+4 is loaded while stage i is consumed and stage i+1 read ahead
+static constexpr int RING_SLOTS = 4;     // power of two; stage i+3 is loaded while stage i is consumed and stage i+1 read ahead
 static constexpr int TILE_PTS = 128;
 static constexpr int ZBUF_BYTES = 16384; // per wave: 16 k-steps x 64 lanes x 16 B (256 latent channels)
 static constexpr int LDS_RING = 0;
@@ -304,9 +304,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         { unsigned long long _t2; STAMP(_t2); st_acc[9] += _t2 - _ti; }
 #endif
         if (Q == 3) {
-            ld_slot = (ld_slot + 1 == RING_SLOTS) ? 0 : ld_slot + 1;
+            ld_slot = (ld_slot + 1) & (RING_SLOTS - 1);
             ++ld_idx;
-            if (ld_rep < a.NS) {
+            if (!MULTIVIEW) {
+                if (ld_idx == a.P1 + a.P2) ld_idx = 0;
+            } else if (ld_rep < a.NS) {
                 if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
             } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
             dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
@@ -315,8 +317,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
     // Stage protocol.  On entry to stage i its fragments are PUBLISHED (all waves' DMA landed + a barrier passed)
     // and its first 8 fragments sit in registers A[0..7].  begin_stage(): wait until this wave's DMA of stage i+1
-    // has landed (the 8 younger pieces = stages i+2, i+3 may stay in flight), barrier => stage i+1 is published and
-    // may be read ahead into A during stage i.  During stage i every wave issues its 4 pieces of stage i+4, one after
+    // has landed (the 4 younger pieces = stage i+2 may stay in flight), barrier => stage i+1 is published and
+    // may be read ahead into A during stage i.  During stage i every wave issues its 4 pieces of stage i+3, one after
     // MFMAs 1, 5, 9, 13 (PNR_DMA).  That slot held stage i-1, whose last readers passed the barrier of stage i.
     frag_t A[8];
     const char* cur;    // this lane's read base of the stage being consumed
@@ -324,19 +326,19 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     auto begin_stage = [&]() {
 #ifdef PNR_STAMPS_FINE
         unsigned long long _tb; STAMP(_tb);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         { unsigned long long _t2; STAMP(_t2); st_acc[8] += _t2 - _tb; _tb = _t2; }
         __builtin_amdgcn_s_barrier();
         { unsigned long long _t2; STAMP(_t2); st_acc[10] += _t2 - _tb; }
 #else
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #ifndef PNR_X_NOBARRIER      // timing experiment only
         __builtin_amdgcn_s_barrier();
 #endif
 #endif
         asm volatile("" ::: "memory");
         cur = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
-        st_slot = (st_slot + 1 == RING_SLOTS) ? 0 : st_slot + 1;
+        st_slot = (st_slot + 1) & (RING_SLOTS - 1);
         nxt = smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16;
     };
     // fragment f of the current stage is in A[f & 7]; after using it, refill the register 8 fragments ahead
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             if (q == 2) issue_piece(std::integral_constant<int, 2>{});
             if (q == 3) issue_piece(std::integral_constant<int, 3>{});
         }
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // stage 0 landed
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // stage 0 landed (stages 1, 2 may be in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
