@@ -249,15 +249,22 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 // lds_dst + 1024 Q + 16 l (the instruction offset applies to both addresses).  Inline asm so that hipcc neither counts
 // these loads in its own vmcnt bookkeeping nor drains them before barriers / ds_reads; they are retired by the counted
 // s_waitcnt in begin_stage (cdna_hip_programming.md §5.7).  A piece costs the wave ~16 issue cycles plus ~4 per scalar
-// instruction around it, so: M0 is (re)written in the same statement but not saved/restored (nothing else in this
-// kernel uses M0 — build_native.py checks the ISA), the per-piece addresses come from the immediate offset, and the 4
-// pieces a wave owes per stage are spread between the stage's MFMAs.
+// instruction around it, so: M0 is written once per stage and not saved/restored, the per-piece addresses come from
+// the immediate offset, and the 4 pieces a wave owes per stage are spread between the stage's MFMAs.
 template <int Q>
 __device__ __forceinline__ void glds_piece(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
+    // M0 (LDS destination base) is written with piece 0 and stays valid for pieces 1..3 of the stage: no other
+    // instruction of this kernel touches M0 (asserted on the ISA by build_native.py).
     if (Q == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+#ifdef PNR_X_M0_EACH      // A/B experiment: rewrite M0 with every piece
     if (Q == 1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
     if (Q == 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
     if (Q == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+#else
+    if (Q == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane_off), "s"(g_base) : "memory");
+    if (Q == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane_off), "s"(g_base) : "memory");
+    if (Q == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane_off), "s"(g_base) : "memory");
+#endif
 }
 
 // Diagnostic build only (-DPNR_STAMPS): per-section shader-cycle sums, never part of the product library.
@@ -343,6 +350,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
     // fragment f of the current stage is in A[f & 7]; after using it, refill the register 8 fragments ahead
 #define PNR_REFILL(f) A[(f) & 7] = *(const frag_t*)(((f) < 8 ? cur : nxt) + (((f) + 8) & 15) * 1024)
+    // fragments f..f+3 have landed once at most 4 younger LDS reads are outstanding: one wait per 4 MFMAs instead of
+    // the per-MFMA waits hipcc would insert (s_waitcnt simm16 0xC47F = lgkmcnt(4), vmcnt/expcnt untouched)
+#ifdef PNR_X_NO_LDSWAIT   // A/B experiment: leave the LDS waits to hipcc (one per MFMA)
+#define PNR_LDSWAIT(f) do { } while (0)
+#else
+#define PNR_LDSWAIT(f) do { if (((f) & 3) == 0) __builtin_amdgcn_s_waitcnt(0xC47F); } while (0)
+#endif
 #define PNR_DMA(f) do { if ((f) == 1) issue_piece(std::integral_constant<int, 0>{}); else if ((f) == 5) issue_piece(std::integral_constant<int, 1>{}); \
                         else if ((f) == 9) issue_piece(std::integral_constant<int, 2>{}); else if ((f) == 13) issue_piece(std::integral_constant<int, 3>{}); } while (0)
 
@@ -371,6 +385,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         begin_stage();
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
+            PNR_LDSWAIT(f);
             x[f] = NM::mfma(A[f & 7], B, x[f]);
             PNR_REFILL(f); PNR_DMA(f);
         }
@@ -411,6 +426,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             begin_stage();
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
+                PNR_LDSWAIT(f);
                 acc = NM::mfma(A[f & 7], xb[8 * half + (f >> 1)][f & 1], acc);
                 PNR_REFILL(f); PNR_DMA(f);
             }
@@ -558,6 +574,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #pragma unroll
                         for (int f = 0; f < 16; ++f) {
                             const int tn = 8 * half + (f >> 1);
+                            PNR_LDSWAIT(f);
                             x[tn] = NM::mfma(A[f & 7], hb[f & 1], x[tn]);
                             PNR_REFILL(f); PNR_DMA(f);
                         }
@@ -640,6 +657,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     asm volatile("" :: "v"(A[0].x), "v"(A[1].x), "v"(A[2].x), "v"(A[3].x), "v"(A[4].x), "v"(A[5].x), "v"(A[6].x), "v"(A[7].x));
 }
 #undef PNR_REFILL
+#undef PNR_LDSWAIT
 #undef PNR_DMA
 
 // ---------------------------------------------------------------------------- host side
