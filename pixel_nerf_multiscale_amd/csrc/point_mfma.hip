@@ -51,6 +51,7 @@ template <> struct Num<PNR_BF16> {
     static __device__ __forceinline__ float lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
     static __device__ __forceinline__ float hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
     static __device__ __forceinline__ uint16_t one() { return 0x3F80; }
+    static __device__ __forceinline__ uint32_t sat(uint32_t p) { return p; }   // bf16 has fp32's range
     static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
     static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
     // relu(pack(a0, a1)) straight from two accumulator (AGPR) registers, as ONE asm statement: hipcc cannot pull the
@@ -73,12 +74,19 @@ template <> struct Num<PNR_F16> {
     static __device__ __forceinline__ float lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
     static __device__ __forceinline__ float hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
     static __device__ __forceinline__ uint16_t one() { return 0x3C00; }
+    static __device__ __forceinline__ uint32_t sat(uint32_t p) {          // see snap2
+        s16x2 v = __builtin_bit_cast(s16x2, p);
+        s16x2 m = {0x7BFF, 0x7BFF};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, m));
+    }
     static __device__ __forceinline__ uint16_t cvt(float a) { return (uint16_t)(pack(a, 0.f) & 0xffff); }
     static __device__ __forceinline__ float back(uint16_t v) { return lo(v); }
     static __device__ __forceinline__ uint32_t snap2(float a0, float a1) {
         uint32_t out, tmp;
-        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0"
-                     : "=&v"(out), "=&v"(tmp) : "a"(a0), "a"(a1));
+        // after the relu every half is a non-negative fp16, whose integer order is its float order: min with 0x7BFF
+        // (65504) saturates +inf (and NaN) instead of letting an overflowing activation poison the next layer
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_min_i16 %0, %0, %4"
+                     : "=&v"(out), "=&v"(tmp) : "a"(a0), "a"(a1), "v"(0x7BFF7BFFu));
         return out;
     }
     static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
@@ -562,10 +570,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     frag_t hb[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        hb[s].x = relu_pk(NM::pack(hacc[8 * s + 0], hacc[8 * s + 1]));
-                        hb[s].y = relu_pk(NM::pack(hacc[8 * s + 2], hacc[8 * s + 3]));
-                        hb[s].z = relu_pk(NM::pack(hacc[8 * s + 4], hacc[8 * s + 5]));
-                        hb[s].w = relu_pk(NM::pack(hacc[8 * s + 6], hacc[8 * s + 7]));
+                        hb[s].x = NM::sat(relu_pk(NM::pack(hacc[8 * s + 0], hacc[8 * s + 1])));
+                        hb[s].y = NM::sat(relu_pk(NM::pack(hacc[8 * s + 2], hacc[8 * s + 3])));
+                        hb[s].z = NM::sat(relu_pk(NM::pack(hacc[8 * s + 4], hacc[8 * s + 5])));
+                        hb[s].w = NM::sat(relu_pk(NM::pack(hacc[8 * s + 6], hacc[8 * s + 7])));
                     }
                     hacc = load_hbias(b, (c + 1) & 15);          // next chunk's bias while fc_1 runs
 #pragma unroll

@@ -71,7 +71,8 @@ class PixelNeRFNet(torch.nn.Module):
         self.d_in, self.d_out, self.d_latent = d_in, d_out, d_latent
         self.num_objs = 0
         self.num_views_per_obj = 1
-        # arithmetic of the fc layers: "auto" = bf16 MFMA kernel when the shape allows, else the fp32 HIP path
+        # arithmetic of the fc layers: "auto" = fp16 MFMA kernel (fp32 accumulate, saturating activations; same speed as
+        # bf16 and ~18 dB closer to the fp32 reference) when the shape allows, else the fp32 HIP path
         self.precision = conf.get_string("precision", os.environ.get("PNR_PRECISION", "auto"))
         self._pack_cache = {}
         self._ws = None
@@ -123,7 +124,7 @@ class PixelNeRFNet(torch.nn.Module):
         p = self.precision
         mlp = mlp if mlp is not None else self.mlp_coarse
         if p == "auto":
-            return "bf16" if mfma_supported(mlp, self) else "fp32"
+            return "fp16" if mfma_supported(mlp, self) else "fp32"
         if p not in N.PRECISIONS:
             raise ValueError(f"unknown precision {p!r}")
         return p
