@@ -51,6 +51,25 @@ def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
     return 2 * (NS * per_view + per_pt)
 
 
+def pmc_traffic_bytes(workload, precision):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary of THIS workload
+    (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh; separate --pmc passes):
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 tallies the
+    128-B requests of wide coalesced reads at 64 B).  None when no summary matches (other workloads / precisions)."""
+    if workload != DEFAULT or precision != "bf16":
+        return None
+    path = os.path.join(ROOT, "profiles", "latest_pmc_bench_default.txt")
+    try:
+        vals = {}
+        for line in open(path):
+            parts = line.split()
+            if len(parts) >= 4 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[parts[1]] = float(parts[3].split("=")[1])
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def build(workload, precision, device, rank_rays_scale=1, seed=0):
     """Random-init network of the reference architecture + synthetic latents/cameras/rays (no dataset, no checkpoint)."""
     import golden_util as gu
@@ -104,7 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,7 +197,7 @@ def main():
                    "samples_per_ray": spec["Kc"] + spec["Kf"], "n_coarse": spec["Kc"], "n_fine": spec["Kf"],
                    "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
         "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic_bytes(args.workload, args.precision),
                      "kernel_ms": k_ms, "flops_per_launch": flops_launch},
     }
     if rank == 0 and world == 1 and args.cpu_rays > 0:
