@@ -476,24 +476,38 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 if (lo < hi) {
                     const Taps tp = bilinear_taps(pu, pv, W, H);
                     const char* lb = a.lat + a.lat_off[lvl] + (size_t)view * H * W * C * 2;
-                    for (int ch = lo + 8 * h; ch < hi; ch += 16) {
-                        float acc8[8];
+                    // 4 k-steps (16 tap loads) in flight per iteration: the loop is latency-bound on L2 otherwise
+                    for (int chb = lo + 8 * h; chb < hi; chb += 64) {
+                        uint4 q[4][4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+                        for (int u = 0; u < 4; ++u) {
+                            const int ch = (chb + 16 * u < hi) ? chb + 16 * u : chb;       // clamp: level widths are multiples of 16
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint4 q = *(const uint4*)(lb + ((size_t)tp.off[i] * C + (ch - ch0)) * 2);
-                            const float w = tp.w[i];
-                            acc8[0] += NM::lo(q.x) * w; acc8[1] += NM::hi(q.x) * w;
-                            acc8[2] += NM::lo(q.y) * w; acc8[3] += NM::hi(q.y) * w;
-                            acc8[4] += NM::lo(q.z) * w; acc8[5] += NM::hi(q.z) * w;
-                            acc8[6] += NM::lo(q.w) * w; acc8[7] += NM::hi(q.w) * w;
+                            for (int i = 0; i < 4; ++i)
+                                q[u][i] = *(const uint4*)(lb + ((size_t)tp.off[i] * C + (ch - ch0)) * 2);
                         }
-                        uint4 o;
-                        o.x = NM::pack(acc8[0], acc8[1]); o.y = NM::pack(acc8[2], acc8[3]);
-                        o.z = NM::pack(acc8[4], acc8[5]); o.w = NM::pack(acc8[6], acc8[7]);
-                        const int ks = (ch - grp * 256) >> 4;
-                        *(uint4*)(zwave + ks * 1024 + lane * 16) = o;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ch = chb + 16 * u;
+                            if (ch < hi) {
+                                float acc8[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float w = tp.w[i];
+                                    acc8[0] += NM::lo(q[u][i].x) * w; acc8[1] += NM::hi(q[u][i].x) * w;
+                                    acc8[2] += NM::lo(q[u][i].y) * w; acc8[3] += NM::hi(q[u][i].y) * w;
+                                    acc8[4] += NM::lo(q[u][i].z) * w; acc8[5] += NM::hi(q[u][i].z) * w;
+                                    acc8[6] += NM::lo(q[u][i].w) * w; acc8[7] += NM::hi(q[u][i].w) * w;
+                                }
+                                uint4 o;
+                                o.x = NM::pack(acc8[0], acc8[1]); o.y = NM::pack(acc8[2], acc8[3]);
+                                o.z = NM::pack(acc8[4], acc8[5]); o.w = NM::pack(acc8[6], acc8[7]);
+                                const int ks = (ch - grp * 256) >> 4;
+                                *(uint4*)(zwave + ks * 1024 + lane * 16) = o;
+                            }
+                        }
                     }
                 }
                 ch0 += C;
@@ -670,12 +684,16 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 
 // ---------------------------------------------------------------------------- host side
 static int num_cus() {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    // immutable per-device property, cached (hipGetDeviceProperties is slow); not library state in the sense of pnr.h
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
     }
-    return n > 0 ? n : 256;
+    return cached[dev];
 }
 static constexpr int MAX_GRID = 512;
 
