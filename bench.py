@@ -35,6 +35,8 @@ WORKLOADS = {
                                             radius=2.0, z=(1.25, 2.75), white=True, lindisp=False, cv=False),
     "nmr_3view_64x64_k64+32": dict(side=64, Kc=64, Kf=32, Kfd=16, NS=3, lat=[(256, 8, 8)], focal=120.0,
                                    radius=2.7, z=(1.2, 4.0), white=True, lindisp=False, cv=False),
+    "dtu_3view_400x300_k128": dict(side=(400, 300), Kc=128, Kf=0, Kfd=0, NS=3, lat=[(256, 19, 25)], focal=360.0,
+                                   radius=2.0, z=(0.1, 5.0), white=False, lindisp=True, cv=False),
     "multiscale_cars_2view_128x128_k64+32": dict(side=128, Kc=64, Kf=32, Kfd=16, NS=2,
                                                  lat=[(64, 64, 64), (64, 64, 64), (128, 32, 32), (256, 16, 16)],
                                                  focal=131.25, radius=1.3, z=(0.8, 1.8), white=True, lindisp=False, cv=True),
@@ -75,8 +77,9 @@ def build(workload, precision, device, rank_rays_scale=1, seed=0):
     import golden_util as gu
     from hip_util import build_net, build_renderer
     w = WORKLOADS[workload]
+    W_img, H_img = w["side"] if isinstance(w["side"], tuple) else (w["side"], w["side"])
     spec = dict(gu._BASE)
-    spec.update(seed=100 + seed, d_hidden=512, lat=w["lat"], NS=w["NS"], SB=1, image=(w["side"], w["side"]),
+    spec.update(seed=100 + seed, d_hidden=512, lat=w["lat"], NS=w["NS"], SB=1, image=(W_img, H_img),
                 focal=w["focal"], N=0, Kc=w["Kc"], Kf=w["Kf"], Kfd=w["Kfd"], depth_std=0.01, lindisp=w["lindisp"],
                 white_bkgd=w["white"], use_code_viewdirs=w["cv"], z_near=w["z"][0], z_far=w["z"][1], radius=w["radius"])
     poses = np.stack([gu.pose_spherical(30.0 * v, -20.0, w["radius"]) for v in range(w["NS"])])[None]
@@ -84,7 +87,7 @@ def build(workload, precision, device, rank_rays_scale=1, seed=0):
     rend = build_renderer(spec, device)
     from pixel_nerf_multiscale_amd import util
     tgt = util.pose_spherical(75.0, -25.0, w["radius"])[None].to(device)
-    rays = util.gen_rays(tgt, w["side"], w["side"], torch.tensor(w["focal"]), w["z"][0], w["z"][1]).reshape(1, -1, 8)
+    rays = util.gen_rays(tgt, W_img, H_img, torch.tensor(w["focal"]), w["z"][0], w["z"][1]).reshape(1, -1, 8)
     if rank_rays_scale > 1:
         rays = rays.repeat(1, rank_rays_scale, 1)
     return spec, net, rend, rays.contiguous()

@@ -197,6 +197,31 @@ class NeRFRenderer(torch.nn.Module):
             res.fine = self._format_outputs(self.composite(model, r, z_all, coarse=False, sb=SB), SB, want_weights)
         return res
 
+    # ------------------------------------------------------------------ whole-frame entry
+    def render_image(self, net, pose, width, height, focal, z_near, z_far, c=None):
+        """One target view in one call — what the eval drivers do per frame (reference eval/eval.py:250-293:
+        gen_rays on the host, H2D, split into ray batches, render_par per chunk with a .cpu() sync each):
+        rays are generated on the GPU (pnr_gen_rays), the whole frame is one pnr_render, nothing touches the host.
+        pose: (4,4) camera-to-world.  Returns rgb (H, W, 3), depth (H, W) on the device."""
+        from .. import util
+        dev = net.poses.device
+        rays = util.gen_rays_device(pose, width, height, focal, z_near, z_far, c=c, device=dev)
+        out = self(net, rays[None])
+        lvl = out.fine if self.using_fine else out.coarse
+        return lvl.rgb.reshape(height, width, 3), lvl.depth.reshape(height, width)
+
+    @staticmethod
+    def frame_to_host_async(rgb, depth):
+        """Asynchronous D2H of a rendered frame into pinned host buffers (instead of the reference's per-chunk
+        blocking .cpu(), eval.py:281-282).  Returns (rgb_host, depth_host, event); event.synchronize() before reading."""
+        rgb_h = torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True)
+        depth_h = torch.empty(depth.shape, dtype=depth.dtype, pin_memory=True)
+        rgb_h.copy_(rgb, non_blocking=True)
+        depth_h.copy_(depth, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(rgb.device))
+        return rgb_h, depth_h, ev
+
     def _format_outputs(self, rendered, superbatch_size, want_weights=False):
         weights, rgb, depth = rendered
         if superbatch_size > 0:

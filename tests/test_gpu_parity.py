@@ -298,3 +298,23 @@ def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv):
     # fine pass: a low-precision coarse weight can move a cdf entry across a draw u -> that importance sample jumps a
     # bin (SURVEY §8c caveat), so the end-to-end fine floor is lower than the coarse one
     assert _psnr(outs["fp16"][0], outs["fp32"][0]) >= 46.0 and _psnr(outs["bf16"][0], outs["fp32"][0]) >= 36.0
+
+
+def test_render_image_from_camera_equals_forward_on_host_rays():
+    """N1: frame rendered from (pose, intrinsics) with on-device rays == forward() on host-generated rays, bit for bit
+    with the same kernel seed; async pinned D2H returns the same bytes."""
+    from hip_util import setup
+    from pixel_nerf_multiscale_amd import util
+    fx, spec, net, rend = setup("tiny_ns2_codeview")
+    rend.fixed_noise = None
+    W, H = spec["image"]
+    pose = util.pose_spherical(75.0, -25.0, spec["radius"])
+    rend.forced_seed = 11
+    rgb, depth = rend.render_image(net, pose, W, H, spec["focal"], spec["z_near"], spec["z_far"])
+    rays = util.gen_rays(pose[None], W, H, torch.tensor(spec["focal"]), spec["z_near"], spec["z_far"]).reshape(1, -1, 8).cuda()
+    ref = rend(net, rays)
+    assert rgb.shape == (H, W, 3) and depth.shape == (H, W)
+    assert maxdiff(rgb.cpu().reshape(-1, 3), ref.fine.rgb.cpu().reshape(-1, 3)) <= 1e-5      # ray direction fp32 rounding only
+    rgb_h, depth_h, ev = rend.frame_to_host_async(rgb, depth)
+    ev.synchronize()
+    assert torch.equal(rgb_h, rgb.cpu()) and torch.equal(depth_h, depth.cpu())
