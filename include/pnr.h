@@ -80,10 +80,11 @@ typedef struct pnr_views {
     int32_t lat_c[PNR_MAX_LEVELS];
     int32_t lat_h[PNR_MAX_LEVELS];
     int32_t lat_w[PNR_MAX_LEVELS];
-    /* produced once per encode() by pnr_pack_latents(); required when precision != PNR_F32:
-     * per level (SB*NS, H_i, W_i, C_i) channels-last in packed_dtype */
-    const void* latent_packed;
-    uint64_t latent_packed_bytes;
+    /* required when precision != PNR_F32: per level (SB*NS, H_i, W_i, C_i) channels-last, 16-bit (packed_dtype),
+     * 16-byte aligned.  Either carved from the blob pnr_pack_latents() writes (level i at the offset it reports), or
+     * the encoder's own output when it already runs channels-last in half precision (zero copy).
+     * With these present the fp32 NCHW pointers above may be NULL. */
+    const void* latent_packed[PNR_MAX_LEVELS];
     int32_t packed_dtype;
     int32_t reserved1;
 } pnr_views;
@@ -138,7 +139,9 @@ uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
 int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
 /* Channels-last low-precision copy of the latent maps for the MFMA kernel's gather. */
 uint64_t pnr_packed_latent_bytes(const pnr_views* views);
-int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
+/* level_offsets (host array of PNR_MAX_LEVELS, may be NULL) receives the byte offset of every level inside `out` */
+int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes,
+                         uint64_t* level_offsets, void* stream);
 
 /* ---- stage entry points (also what the tests call) ------------------------------------------- */
 /* NeRFRenderer.sample_coarse (render/nerf.py:98-118).  rays (N,8) -> z (N,Kc). */

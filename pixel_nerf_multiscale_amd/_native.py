@@ -40,7 +40,7 @@ class pnr_views(C.Structure):
         ("n_focal", C.c_int32), ("n_c", C.c_int32), ("n_levels", C.c_int32), ("reserved0", C.c_int32),
         ("latent", _fp * PNR_MAX_LEVELS),
         ("lat_c", C.c_int32 * PNR_MAX_LEVELS), ("lat_h", C.c_int32 * PNR_MAX_LEVELS), ("lat_w", C.c_int32 * PNR_MAX_LEVELS),
-        ("latent_packed", _fp), ("latent_packed_bytes", C.c_uint64), ("packed_dtype", C.c_int32), ("reserved1", C.c_int32),
+        ("latent_packed", _fp * PNR_MAX_LEVELS), ("packed_dtype", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -70,7 +70,7 @@ PROTOTYPES = {
     "pnr_packed_mlp_bytes": (_u64, [C.POINTER(pnr_mlp)]),
     "pnr_pack_mlp": (_i32, [C.POINTER(pnr_mlp), _i32, _fp, _u64, _fp]),
     "pnr_packed_latent_bytes": (_u64, [C.POINTER(pnr_views)]),
-    "pnr_pack_latents": (_i32, [C.POINTER(pnr_views), _i32, _fp, _u64, _fp]),
+    "pnr_pack_latents": (_i32, [C.POINTER(pnr_views), _i32, _fp, _u64, C.POINTER(C.c_uint64), _fp]),
     "pnr_sample_coarse": (_i32, [_fp, _i64, _i32, _i32, _fp, _u64, _i64, _fp, _fp]),
     "pnr_composite": (_i32, [_fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp]),
     "pnr_sample_fine": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _i32, _f, _i32, _fp, _fp, _fp, _u64, _i64, _fp, _fp]),

@@ -45,7 +45,7 @@ static int32_t check_model(const pnr_params* prm, const pnr_mlp* mlp, const pnr_
     if (vw->n_levels < 1 || vw->n_levels > PNR_MAX_LEVELS) return PNR_E_SHAPE;
     int L = 0;
     for (int i = 0; i < vw->n_levels; ++i) {
-        if (!vw->latent[i]) return PNR_E_NULL;
+        if (prm->precision == PNR_F32 ? !vw->latent[i] : (!vw->latent[i] && !vw->latent_packed[i])) return PNR_E_NULL;
         if (vw->lat_c[i] < 1 || vw->lat_h[i] < 2 || vw->lat_w[i] < 2) return PNR_E_SHAPE;  // (W-1) divides uv
         L += vw->lat_c[i];
     }

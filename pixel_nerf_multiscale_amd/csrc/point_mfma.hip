@@ -214,7 +214,7 @@ __host__ __device__ inline LatPack lat_layout(const pnr_views& v) {
         p.off[i] = o;
         if (i < v.n_levels) o += (((uint64_t)nv * v.lat_c[i] * v.lat_h[i] * v.lat_w[i] * 2) + 255) & ~(uint64_t)255;
     }
-    p.total = o + 64;   // tail pad: 16-B tap loads never run past the allocation
+    p.total = o;
     return p;
 }
 
@@ -239,8 +239,7 @@ struct MfmaArgs {
     int64_t n_points, pts_per_obj;
     const char* stream;
     const float* btab;
-    const char* lat;               // packed latents
-    uint64_t lat_off[PNR_MAX_LEVELS];
+    const char* lat[PNR_MAX_LEVELS];   // packed latents per level
     float* out;
     float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
     int n_tiles, NS, combine_max;
@@ -475,7 +474,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 const int hi = (ch0 + C) < (grp + 1) * 256 ? (ch0 + C) : (grp + 1) * 256;
                 if (lo < hi) {
                     const Taps tp = bilinear_taps(pu, pv, W, H);
-                    const char* lb = a.lat + a.lat_off[lvl] + (size_t)view * H * W * C * 2;
+                    const char* lb = a.lat[lvl] + (size_t)view * H * W * C * 2;
                     // 4 k-steps (16 tap loads) in flight per iteration: the loop is latency-bound on L2 otherwise
                     for (int chb = lo + 8 * h; chb < hi; chb += 64) {
                         uint4 q[4][4];
@@ -709,11 +708,12 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     if (!make_layout(*mlp, y)) return PNR_E_UNSUPPORTED;
     if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
     if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
-    LatPack lp = lat_layout(*vw);
-    if (!vw->latent_packed || vw->packed_dtype != prm->precision || vw->latent_packed_bytes < lp.total) return PNR_E_PACKED;
-    if (((uintptr_t)vw->latent_packed & 15) != 0) return PNR_E_ALIGN;
-    for (int i = 0; i < vw->n_levels; ++i)
+    if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
+    for (int i = 0; i < vw->n_levels; ++i) {
+        if (!vw->latent_packed[i]) return PNR_E_PACKED;
+        if (((uintptr_t)vw->latent_packed[i] & 15) != 0) return PNR_E_ALIGN;
         if (vw->lat_c[i] % 16 != 0) return PNR_E_UNSUPPORTED;
+    }
     if (ws_bytes < point_mfma_workspace_bytes(mlp, vw)) return PNR_E_WORKSPACE;
     if (vw->n_views > 1 && y.nb1 == 0) return PNR_E_UNSUPPORTED;     // reduction before the first block
     if (prm->use_code_viewdirs ? (mlp->d_in != 6 + 12 * prm->num_freqs) : (mlp->d_in != 6 + 6 * prm->num_freqs)) return PNR_E_SHAPE;
@@ -722,8 +722,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.vw = *vw; a.src = src; a.n_points = n_points; a.pts_per_obj = pts_per_obj;
     a.btab = (const float*)mlp->packed;
     a.stream = (const char*)mlp->packed + y.btab_bytes;
-    a.lat = (const char*)vw->latent_packed;
-    for (int i = 0; i < PNR_MAX_LEVELS; ++i) a.lat_off[i] = lp.off[i];
+    for (int i = 0; i < PNR_MAX_LEVELS; ++i) a.lat[i] = (const char*)vw->latent_packed[i];
     a.out = out;
     a.spill = (float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
@@ -791,7 +790,8 @@ extern "C" uint64_t pnr_packed_latent_bytes(const pnr_views* views) {
     return lat_layout(*views).total;
 }
 
-extern "C" int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes, void* stream) {
+extern "C" int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void* out, uint64_t out_bytes,
+                                    uint64_t* level_offsets, void* stream) {
     if (!views || !out) return PNR_E_NULL;
     if (views->n_levels < 1 || views->n_levels > PNR_MAX_LEVELS) return PNR_E_SHAPE;
     if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
@@ -799,6 +799,8 @@ extern "C" int32_t pnr_pack_latents(const pnr_views* views, int32_t dtype, void*
     LatPack lp = lat_layout(*views);
     if (out_bytes < lp.total) return PNR_E_WORKSPACE;
     if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    if (level_offsets)
+        for (int i = 0; i < PNR_MAX_LEVELS; ++i) level_offsets[i] = lp.off[i];
     if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_latents<PNR_BF16>, dim3(1024), dim3(256), 0, (hipStream_t)stream, *views, lp, (char*)out);
     else hipLaunchKernelGGL(k_pack_latents<PNR_F16>, dim3(1024), dim3(256), 0, (hipStream_t)stream, *views, lp, (char*)out);
     PNR_LAUNCH_CHECK();

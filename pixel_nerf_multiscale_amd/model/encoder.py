@@ -72,14 +72,30 @@ class SpatialEncoder(nn.Module):
         self.latent_size = sizes if use_multi_scale else sizes[-1]
         self.latent = None      # plain attributes, like the reference (encoder.py:106-107)
         self.latents = []
+        # N2: None = fp32 NCHW trunk (reference numerics).  torch.float16 / torch.bfloat16 = run the trunk under autocast
+        # in channels_last; its outputs are then ALREADY the (view, H, W, C) 16-bit images the render kernel gathers
+        # from, and are handed over without a repack (pnr_views.latent_packed).
+        self.half_dtype = None
+        self._level_maps16 = None
 
     def forward(self, x):
         x = x * self.feature_scale
         feats = []
-        for layer in self.layers:
-            x = layer(x)
-            feats.append(x)
-        self.set_latents(feats if self.use_multi_scale else [feats[-1]])
+        if self.half_dtype is not None and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+            with torch.autocast("cuda", dtype=self.half_dtype):
+                for layer in self.layers:
+                    x = layer(x)
+                    feats.append(x)
+            feats = feats if self.use_multi_scale else [feats[-1]]
+            maps16 = [f.to(self.half_dtype).contiguous(memory_format=torch.channels_last) for f in feats]
+            self.set_latents([m.float() for m in maps16])
+            self._level_maps16 = [m.detach() for m in maps16]
+        else:
+            for layer in self.layers:
+                x = layer(x)
+                feats.append(x)
+            self.set_latents(feats if self.use_multi_scale else [feats[-1]])
         return self.latents if self.use_multi_scale else self.latent
 
     def set_latents(self, maps):
@@ -88,11 +104,19 @@ class SpatialEncoder(nn.Module):
         self.latents = maps if self.use_multi_scale else []
         self.latent = maps[-1]
         self._level_maps = maps
+        self._level_maps16 = None
 
     def level_maps(self):
         if self.latent is None:
             raise RuntimeError("encoder has no latent yet: call PixelNeRFNet.encode() first")
         return self.latents if self.use_multi_scale else [self.latent]
+
+    def level_maps16(self, dtype):
+        """Channels-last 16-bit maps left by a half-precision forward(), if they match `dtype`; else None."""
+        m = self._level_maps16
+        if m is None or m[0].dtype != dtype:
+            return None
+        return m
 
     def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
         raise RuntimeError(

@@ -202,17 +202,31 @@ class PixelNeRFNet(torch.nn.Module):
             v.latent[i] = N.ptr(mp)
             v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
         if precision != "fp32":
-            key = ("lat", precision, tuple((mp.data_ptr(), mp._version, tuple(mp.shape)) for mp in maps))
-            packed = self._pack_cache.get(key)
-            if packed is None:
-                self._pack_cache = {k: t for k, t in self._pack_cache.items() if k[0] != "lat"}
-                nbytes = N.lib.pnr_packed_latent_bytes(C.byref(v))
-                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                N.check(N.lib.pnr_pack_latents(C.byref(v), N.PRECISIONS[precision], packed.data_ptr(), nbytes,
-                                               N.current_stream(dev)), "pnr_pack_latents")
-                self._pack_cache[key] = packed
-            v.latent_packed, v.latent_packed_bytes, v.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
-            keep.append(packed)
+            tdt = torch.float16 if precision in ("fp16", "f16") else torch.bfloat16
+            maps16 = self.encoder.level_maps16(tdt)
+            if maps16 is not None:
+                # the trunk already produced channels-last 16-bit maps: hand their storage over as is (N2)
+                for i, m16 in enumerate(maps16):
+                    assert m16.is_contiguous(memory_format=torch.channels_last) and m16.data_ptr() % 16 == 0
+                    v.latent_packed[i] = m16.data_ptr()
+                    keep.append(m16)
+            else:
+                key = ("lat", precision, tuple((mp.data_ptr(), mp._version, tuple(mp.shape)) for mp in maps))
+                cached = self._pack_cache.get(key)
+                if cached is None:
+                    self._pack_cache = {k: t for k, t in self._pack_cache.items() if k[0] != "lat"}
+                    nbytes = N.lib.pnr_packed_latent_bytes(C.byref(v))
+                    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    offs = (C.c_uint64 * N.PNR_MAX_LEVELS)()
+                    N.check(N.lib.pnr_pack_latents(C.byref(v), N.PRECISIONS[precision], packed.data_ptr(), nbytes, offs,
+                                                   N.current_stream(dev)), "pnr_pack_latents")
+                    cached = (packed, list(offs))
+                    self._pack_cache[key] = cached
+                packed, offs = cached
+                for i in range(len(maps)):
+                    v.latent_packed[i] = packed.data_ptr() + offs[i]
+                keep.append(packed)
+            v.packed_dtype = N.PRECISIONS[precision]
         return v, keep
 
     def workspace(self, nbytes, device):

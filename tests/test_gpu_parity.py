@@ -318,3 +318,42 @@ def test_render_image_from_camera_equals_forward_on_host_rays():
     rgb_h, depth_h, ev = rend.frame_to_host_async(rgb, depth)
     ev.synchronize()
     assert torch.equal(rgb_h, rgb.cpu()) and torch.equal(depth_h, depth.cpu())
+
+
+def test_encoder_half_channels_last_latents_are_consumed_without_repack():
+    """N2: the ResNet trunk run in fp16 channels-last leaves latents that ARE the kernel's packed layout; they are
+    handed to libpnr_hip by pointer (no pnr_pack_latents), and the render matches the fp32-trunk + repack route.
+    (The trunk itself is unpinned against torchvision, which is not installed here: parity unpinned for N2.)"""
+    import ctypes as C
+    from hip_util import model_conf, build_renderer
+    import golden_util as gu
+    from pixel_nerf_multiscale_amd import PixelNeRFNet, util
+    spec = dict(gu.CASES["full_ns3"]); spec.update(NS=2, Kf=0, Kfd=0, Kc=32)
+    torch.manual_seed(0)
+    net = PixelNeRFNet(model_conf(spec, "fp16"))
+    for which, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)):
+        mlp.load_state_dict({k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, which).items()})
+    net = net.cuda().eval()
+    W, H = spec["image"]
+    images = torch.rand(1, 2, 3, H, W, device="cuda") * 2 - 1
+    poses = torch.stack([util.pose_spherical(30.0 * v, -20.0, spec["radius"]) for v in range(2)])[None].cuda()
+    rays = util.gen_rays(util.pose_spherical(75.0, -25.0, spec["radius"])[None], W, H, torch.tensor(spec["focal"]),
+                         spec["z_near"], spec["z_far"]).reshape(1, -1, 8)[:, ::3].contiguous().cuda()
+    rend = build_renderer(spec)
+    rend.forced_seed = 3
+    with torch.no_grad():
+        net.encode(images, poses, torch.tensor(spec["focal"]))
+    lat32 = net.encoder.latent.clone()
+    assert lat32.shape == (2, 256, H // 16, W // 16)
+    ref = rend(net, rays).coarse.rgb.cpu()                         # fp32 trunk -> pnr_pack_latents -> fp16 kernel
+    net.encoder.half_dtype = torch.float16
+    with torch.no_grad():
+        net.encode(images, poses, torch.tensor(spec["focal"]))
+    m16 = net.encoder.level_maps16(torch.float16)
+    assert m16 is not None and m16[0].dtype == torch.float16 and m16[0].is_contiguous(memory_format=torch.channels_last)
+    rel = float((m16[0].float() - lat32).abs().max() / lat32.abs().max())
+    assert rel < 2e-2
+    v, keep = net.views_struct("fp16")
+    assert v.latent_packed[0] == m16[0].data_ptr()                 # zero copy
+    out = rend(net, rays).coarse.rgb.cpu()
+    assert _psnr(out, ref) >= 45.0
