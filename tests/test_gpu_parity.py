@@ -357,3 +357,80 @@ def test_encoder_half_channels_last_latents_are_consumed_without_repack():
     assert v.latent_packed[0] == m16[0].data_ptr()                 # zero copy
     out = rend(net, rays).coarse.rgb.cpu()
     assert _psnr(out, ref) >= 45.0
+
+
+@pytest.mark.parametrize("Kc,Kf,Kfd", [(1, 0, 0), (37, 0, 0), (5, 3, 1), (130, 70, 30), (300, 212, 100)])
+def test_stage_kernels_ragged_sample_counts(Kc, Kf, Kfd):
+    """Sample counts that are not multiples of the wave size / not powers of two, one sample per ray, and a merged
+    count above 256 (bitonic padding to 512): stage kernels vs the oracle with identical explicit noise."""
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    g = torch.Generator().manual_seed(Kc * 7 + Kf)
+    N = 67
+    rays = torch.zeros(N, 8)
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    rays[:, 6] = 0.5 + torch.rand(N, generator=g)
+    rays[:, 7] = rays[:, 6] + 1.0 + torch.rand(N, generator=g)
+    n_imp = Kf - Kfd
+    noise = dict(noise_c=torch.rand(N, Kc, generator=g))
+    if n_imp > 0:
+        noise.update(u=torch.rand(N, n_imp, generator=g), r=torch.rand(N, n_imp, generator=g))
+    if Kfd > 0:
+        noise.update(g=torch.randn(N, Kfd, generator=g))
+    rend = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.05, white_bkgd=False).cuda()
+    rend.fixed_noise = {k: v.cuda() for k, v in noise.items()}
+    zc_ref = orc.sample_coarse(rays, Kc, False, noise["noise_c"])
+    zc = rend.sample_coarse(rays.cuda())
+    assert maxdiff(zc.cpu(), zc_ref) <= 1e-5
+    out = torch.rand(N, Kc, 4, generator=g)
+    out[..., 3] *= 25.0
+    w_ref, rgb_ref, d_ref = orc.composite(rays, zc_ref, out, False)
+    w, rgb, d = rend._composite_native(rays.cuda(), zc_ref.cuda().contiguous(), out.cuda())
+    assert maxdiff(w.cpu(), w_ref) <= 5e-6 and maxdiff(rgb.cpu(), rgb_ref) <= 2e-5 and maxdiff(d.cpu(), d_ref) <= 1e-4
+    if Kf > 0:
+        samps = [zc_ref]
+        if n_imp > 0:
+            samps.append(orc.sample_fine(rays, w_ref, Kc, False, noise["u"], noise["r"]))
+        if Kfd > 0:
+            samps.append(orc.sample_fine_depth(rays, d_ref, 0.05, noise["g"]))
+        zf_ref = torch.sort(torch.cat(samps, -1), -1)[0]
+        rend.last_seed = 0
+        zf = rend.sample_fine_sorted(rays.cuda(), zc_ref.cuda(), w_ref.cuda(), d_ref.cuda())
+        # a cdf entry within 1 ulp of a draw may land in the neighbouring bin (documented): allow a handful of samples
+        bad = (zf.cpu() - zf_ref).abs() > 1e-4
+        assert int(bad.sum()) <= max(2, int(2e-4 * zf_ref.numel()))
+
+
+def test_c_abi_error_codes():
+    """Reference convention is a Python assert (nerf.py:269, resnetfc.py:190); the C ABI reports codes, the Python
+    layer raises."""
+    import ctypes as C
+    from hip_util import setup
+    from pixel_nerf_multiscale_amd import _native as N
+    fx, spec, net, rend = setup("full_ns1", precision="bf16")
+    rays = _dev(fx["rays"]).reshape(-1, 8)
+    prm = net.params_struct(rend, "bf16")
+    m, k1 = net.mlp_struct(net.mlp_coarse, "bf16")
+    v, k2 = net.views_struct("bf16")
+    o = N.pnr_outputs()
+    rgb = torch.empty(16, 3, device="cuda"); dep = torch.empty(16, device="cuda")
+    o.coarse_rgb, o.coarse_depth, o.fine_rgb, o.fine_depth = N.ptr(rgb), N.ptr(dep), N.ptr(rgb), N.ptr(dep)
+    nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(m), C.byref(v), 16)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    s = N.current_stream(rays.device)
+    call = lambda p=prm, mm=m, vv=v, nb=nbytes, n=16, per=16: N.lib.pnr_render(
+        C.byref(p), C.byref(mm), None, C.byref(vv), N.ptr(rays), n, per, None, 1, 0, C.byref(o), ws.data_ptr(), nb, s)
+    assert call() == 0
+    assert call(nb=nbytes // 2) == -4                                   # workspace too small
+    assert call(n=16, per=5) == -2                                      # rays not divisible into objects
+    p2 = N.pnr_params.from_buffer_copy(prm); p2.precision = N.PNR_F16
+    assert call(p=p2) == -6                                             # packed for bf16, asked for fp16
+    m2 = N.pnr_mlp.from_buffer_copy(m); m2.packed = None
+    assert call(mm=m2) == -6                                            # packed stream missing
+    m3 = N.pnr_mlp.from_buffer_copy(m); m3.d_in = 41
+    assert call(mm=m3) == -2
+    m4 = N.pnr_mlp.from_buffer_copy(m); m4.combine_type = 7
+    assert call(mm=m4) == -3
+    p5 = N.pnr_params.from_buffer_copy(prm); p5.n_fine_depth = 99
+    assert call(p=p5) == -2
+    assert N.lib.pnr_composite(N.ptr(rays), rays.data_ptr() + 4, rays.data_ptr() + 4, 2, 2, 0, None, N.ptr(rgb), N.ptr(dep), s) == -5
+    torch.cuda.synchronize()

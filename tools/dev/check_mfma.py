@@ -1,6 +1,6 @@
 """Dev helper (GPU box): error of the MFMA path vs reference fixtures, per stage."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import golden_util as gu
