@@ -40,29 +40,9 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if any("point_mfma" in " ".join(j) for j in jobs):
-        check_m0(hipcc, verbose)
     if force or jobs or _newer(objs, LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
-
-
-def check_m0(hipcc, verbose=True):
-    """k_point_mfma writes M0 (LDS-DMA destination) once per stage and relies on nothing else touching it:
-    assert on the generated ISA that every mention of m0 is one of our own `s_mov_b32 m0, sN`."""
-    import re
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, "point_mfma.s")
-        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", asm,
-               os.path.join(CSRC, "point_mfma.hip")]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        bad = [l.strip() for l in open(asm) if re.search(r"\bm0\b", l) and not l.strip().startswith(";")
-               and not re.match(r"\s*s_mov_b32 m0, s\d+\s*$", l)]
-    if bad:
-        raise RuntimeError("unexpected M0 use in point_mfma ISA (LDS-DMA base would be clobbered): " + "; ".join(bad[:5]))
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "pnr_common.h"
+#include "resblock_asm.inc"
 
 namespace pnr {
 
@@ -256,22 +257,18 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 // lds_dst + 1024 Q + 16 l (the instruction offset applies to both addresses).  Inline asm so that hipcc neither counts
 // these loads in its own vmcnt bookkeeping nor drains them before barriers / ds_reads; they are retired by the counted
 // s_waitcnt in begin_stage (cdna_hip_programming.md §5.7).  A piece costs the wave ~16 issue cycles plus ~4 per scalar
-// instruction around it, so: M0 is written once per stage and not saved/restored, the per-piece addresses come from
-// the immediate offset, and the 4 pieces a wave owes per stage are spread between the stage's MFMAs.
+// instruction around it, so the per-piece addresses come from the immediate offset and the 4 pieces a wave owes per
+// stage are spread between the stage's MFMAs.  (The hand-scheduled blocks of resblock_asm.inc save M0 once per block.)
 template <int Q>
 __device__ __forceinline__ void glds_piece(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
-    // M0 (LDS destination base) is written with piece 0 and stays valid for pieces 1..3 of the stage: no other
-    // instruction of this kernel touches M0 (asserted on the ISA by build_native.py).
-    if (Q == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
-#ifdef PNR_X_M0_EACH      // A/B experiment: rewrite M0 with every piece
-    if (Q == 1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
-    if (Q == 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
-    if (Q == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
-#else
-    if (Q == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane_off), "s"(g_base) : "memory");
-    if (Q == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane_off), "s"(g_base) : "memory");
-    if (Q == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane_off), "s"(g_base) : "memory");
-#endif
+    // M0 (the LDS destination base) is compiler-reserved: hipcc keeps its own value there across statements (it indexes
+    // kernel-argument arrays with s_movrels in the gather) and writes it with the same `s_mov_b32 m0, sN` this code
+    // uses, so every piece saves, sets and restores M0 inside its own statement (cdna_hip_programming.md §5.7).
+    uint32_t keep;
+    if (Q == 0) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 1) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 2) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+    if (Q == 3) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
 // Diagnostic build only (-DPNR_STAMPS): per-section shader-cycle sums, never part of the product library.
@@ -300,7 +297,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     __syncthreads();
 
     // ---------------- weight-stream loader: every wave issues 4 x 1 KiB LDS-DMA per stage, PREFETCH+1 stages ahead
+    // loader cursor: stage index in the packed stream, source-view pass it belongs to, and where that pass wraps to 0
+    // (a non-last view repeats phase 1; the last view runs on into phase 2)
     int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
+    int ld_wrap = (a.NS == 1) ? a.P1 + a.P2 : a.P1;
     const uint32_t gl_off = (uint32_t)(wv * 4096 + lane * 16);
     const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
     // piece Q (0..3) of the loader's current stage; the cursor advances after the 4th piece
@@ -320,11 +320,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         if (Q == 3) {
             ld_slot = (ld_slot + 1) & (RING_SLOTS - 1);
             ++ld_idx;
-            if (!MULTIVIEW) {
-                if (ld_idx == a.P1 + a.P2) ld_idx = 0;
-            } else if (ld_rep < a.NS) {
-                if (ld_idx == a.P1) { ++ld_rep; ld_idx = (ld_rep < a.NS) ? 0 : a.P1; }
-            } else if (ld_idx == a.P1 + a.P2) { ld_rep = 0; ld_idx = 0; }
+            if (ld_idx == ld_wrap) {
+                ld_idx = 0;
+                ld_rep = (ld_rep + 1 == a.NS) ? 0 : ld_rep + 1;
+                ld_wrap = (ld_rep == a.NS - 1) ? a.P1 + a.P2 : a.P1;
+            }
             dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
             dma_l = __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES);
         }
@@ -398,7 +398,42 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         }
     };
     // n_lds k-steps whose B fragment is image [k-step][lane] in this wave's LDS buffer, then n_bias bias stages
-    auto x_stages = [&](int n_lds, int n_bias) {
+    // accumulator tiles pinned to a[16t : 16t+15] + the loader/consumer cursor: operand list shared by the two
+    // hand-scheduled blocks of resblock_asm.inc (tools/gen_resblock_asm.py documents the contract)
+#define PNR_ASM_STATE_OPERANDS                                                                                          \
+    "+{a[0:15]}"(x[0]), "+{a[16:31]}"(x[1]), "+{a[32:47]}"(x[2]), "+{a[48:63]}"(x[3]), "+{a[64:79]}"(x[4]),               \
+    "+{a[80:95]}"(x[5]), "+{a[96:111]}"(x[6]), "+{a[112:127]}"(x[7]), "+{a[128:143]}"(x[8]), "+{a[144:159]}"(x[9]),      \
+    "+{a[160:175]}"(x[10]), "+{a[176:191]}"(x[11]), "+{a[192:207]}"(x[12]), "+{a[208:223]}"(x[13]),                    \
+    "+{a[224:239]}"(x[14]), "+{a[240:255]}"(x[15]), "+s"(st_), "+s"(li_), "+s"(ls_), "+s"(lr_), "+s"(lw_)
+    const int asm_cfg = a.P1 | ((a.P1 + a.P2) << 10) | (a.NS << 20);
+    const uint32_t ring_lane = lds_addr(smem + LDS_RING) + lane * 16;
+    auto asm_resync = [&](int st_, int li_, int ls_, int lr_, int lw_) {     // state back from an asm block
+        st_slot = st_; ld_idx = li_; ld_slot = ls_; ld_rep = lr_; ld_wrap = lw_;
+        dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
+        dma_l = __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES);
+#pragma unroll
+        for (int f = 0; f < 8; ++f)                  // the next stage is published: its first 8 fragments into A
+            A[f] = *(const frag_t*)(smem + LDS_RING + st_slot * STAGE_BYTES + lane * 16 + f * 1024);
+    };
+    // n_lds k-steps whose B fragment is image [k-step][lane] in this wave's LDS buffer, then n_bias (0/1) bias stages
+    auto x_stages = [&](int n_lds, int n_bias, bool use_asm = true) {
+#ifndef PNR_NO_ASM_RESBLOCK
+        if (!MULTIVIEW && use_asm) {
+            int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
+            const int cfg2 = n_lds | (n_bias << 8);
+            const uint32_t zaddr = lds_addr(zwave) + lane * 16;
+            if (DT == PNR_BF16)
+                asm volatile(PNR_XSTAGES_ASM_BF16 : PNR_ASM_STATE_OPERANDS
+                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(b_bias.x), "s"(cfg2)
+                             : PNR_RESBLOCK_CLOBBERS);
+            else
+                asm volatile(PNR_XSTAGES_ASM_F16 : PNR_ASM_STATE_OPERANDS
+                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(b_bias.x), "s"(cfg2)
+                             : PNR_RESBLOCK_CLOBBERS);
+            asm_resync(st_, li_, ls_, lr_, lw_);
+            return;
+        }
+#endif
         frag_t Bz = *(const frag_t*)(zwave + lane * 16);
 #pragma unroll 1
         for (int it = 0; it < n_lds + n_bias; ++it) {
@@ -558,7 +593,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) x[t] = zero;
                 }
+#ifdef PNR_X_NO_ASM_LININ
+                x_stages(a.S_in, 0, false);
+#else
                 x_stages(a.S_in, 0);
+#endif
                 if (n_groups == 1) gather(0);
                 STAMP_ACC(2, st_t);
             }
@@ -566,11 +605,32 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             if (b < a.nb1) {
                 for (int grp = 0; grp < n_groups; ++grp) {
                     if (n_groups > 1) gather(grp);
+#ifdef PNR_X_NO_ASM_LINZ
+                    x_stages(16, grp == n_groups - 1 ? 1 : 0, false);
+#else
                     x_stages(16, grp == n_groups - 1 ? 1 : 0);       // last group: + lin_z.bias
+#endif
                 }
             }
             STAMP_ACC(3, st_t);
             // ---- resblock: x += fc_1(relu(fc_0(relu(x)))) + biases  (resnetfc.py:53-62)
+#ifndef PNR_NO_ASM_RESBLOCK
+            if constexpr (!MULTIVIEW) {
+                // hand-scheduled block (tools/gen_resblock_asm.py -> resblock_asm.inc): snapshot, fc_1-bias stage, 16 chunks
+                int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
+                const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + h * 16;
+                if (DT == PNR_BF16)
+                    asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
+                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x)
+                                 : PNR_RESBLOCK_CLOBBERS);
+                else
+                    asm volatile(PNR_RESBLOCK_ASM_F16 : PNR_ASM_STATE_OPERANDS
+                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x)
+                                 : PNR_RESBLOCK_CLOBBERS);
+                asm_resync(st_, li_, ls_, lr_, lw_);
+            } else
+#endif
+            {
             snapshot();
             STAMP_ACC(4, st_t);
             x_stages(0, 1);                       // + fc_1.bias
@@ -601,6 +661,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         }
                     }
                 }
+            }
             }
             STAMP_ACC(6, st_t);
             ++b;

@@ -32,21 +32,11 @@ def zero(sd, pats):
         if any(p in k for p in pats):
             sd[k][...] = 0
 
-import io, contextlib
-def diag(ns, which):
-    def f(sd):
-        zero(sd, ["lin_z", "blocks"])
-        other = "fc_1" if which == "fc_0" else "fc_0"
-        sd[f"blocks.0.{other}.weight"][...] = np.eye(512, dtype=np.float32)
-        for n in ns: sd[f"blocks.0.{which}.weight"][n, n] = 1.0
-    return f
-def entry(which, n, k, val=1.0):
-    def f(sd):
-        zero(sd, ["lin_z", "blocks"])
-        other = "fc_1" if which == "fc_0" else "fc_0"
-        sd[f"blocks.0.{other}.weight"][...] = np.eye(512, dtype=np.float32)
-        sd[f"blocks.0.{which}.weight"][n, k] = val
-    return f
-for which in ("fc_0", "fc_1"):
-    for (n, k) in [(0, 496), (496, 0), (0, 511), (511, 0), (0, 480), (480, 0), (0, 495), (300, 500), (500, 300), (200, 240), (200, 250)]:
-        variant(f"{which} entry ({n},{k})", entry(which, n, k, 2.0))
+variant("lin_in+lin_out only", lambda sd: zero(sd, ["lin_z", "blocks"]))
+variant("+lin_z (no blocks)", lambda sd: zero(sd, ["blocks"]))
+variant("+lin_z.0 only", lambda sd: zero(sd, ["blocks", "lin_z.1", "lin_z.2"]))
+variant("+lin_z.2 only", lambda sd: zero(sd, ["blocks", "lin_z.0", "lin_z.1"]))
+variant("blocks only (no lin_z)", lambda sd: zero(sd, ["lin_z"]))
+variant("block0 only", lambda sd: zero(sd, ["lin_z", "blocks.1", "blocks.2", "blocks.3", "blocks.4"]))
+variant("block4 only", lambda sd: zero(sd, ["lin_z", "blocks.1", "blocks.2", "blocks.3", "blocks.0"]))
+variant("full", lambda sd: None)

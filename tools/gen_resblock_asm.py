@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""
+Generates pixel_nerf_multiscale_amd/csrc/resblock_asm.inc: the resblock of the fused point kernel
+(x += fc_1(relu(fc_0(relu(x)))) + biases, reference resnetfc.py:53-62) as ONE hand-scheduled gfx950 asm block per
+MFMA dtype.  hipcc's version of the same loop runs ~3300 cycles per 64-MFMA chunk (AGPR-tile parking, per-MFMA
+waits, ~50 scalar ops per chunk); this schedule runs ~2400 (tools/dev/ubench).
+
+Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
+  * x tiles are pinned: tile t = a[16t : 16t+15] (operands %0..%15, "+{a[..]}").
+  * entry: the next stage to consume (this block's fc_1-bias stage) is published, DMA of the two stages after it is
+    in flight, nothing is assumed about the A-fragment registers (they are reloaded here).
+  * in/out scalars: %16 st_slot, %17 ld_idx, %18 ld_slot, %19 ld_rep, %20 ld_wrap   (loader cursor, see issue_piece)
+  * inputs: %21 cfg = P1 | (P1+P2)<<10 | NS<<20, %22 stream base (s64), %23 ring LDS base + wave*4096 (s),
+            %24 ring LDS base + lane*16 (v), %25 DMA lane offset wave*4096 + lane*16 (v),
+            %26 LDS address of fc_0.bias[block] + 16*(lane>>5) (v), %27 bias B-fragment dword 0 (v)
+  * exit: all LDS reads drained, accumulators readable, 65 stages consumed, cursor advanced.
+Register use inside (all declared as clobbers): v10-13 slot read bases, v14 bias address, v15 DMA lane offset,
+v16-19 bias B fragment, v40-55 chunk accumulator (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
+v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 tiles x 2 k-steps x 4), s20-s39.
+"""
+import os
+import sys
+
+
+def A(i):
+    return f"v[{96 + 4 * i}:{99 + 4 * i}]"
+
+
+def XB(t, s):
+    b = 128 + (t * 2 + s) * 4
+    return f"v[{b}:{b + 3}]"
+
+
+def gen(dt):
+    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
+    cvt = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[dt]
+    L = []
+    e = L.append
+
+    def relu_pack(dst, a0, a1, tmp):
+        e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
+        e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
+        e(f"{cvt} v{dst}, v{tmp}, v{tmp + 1}")
+        e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
+        if dt == "f16":
+            e(f"v_pk_min_i16 v{dst}, v{dst}, s38")          # saturate +inf/NaN to 65504
+
+    def loader_advance():
+        e("s_add_u32 s21, s21, 1")
+        e("s_add_u32 s24, s24, 0x4000")
+        e("s_addc_u32 s25, s25, 0")
+        e("s_cmp_lg_u32 s21, s29")
+        e("s_cbranch_scc1 2f")
+        e("s_mov_b32 s21, 0")
+        e("s_mov_b64 s[24:25], s[36:37]")
+        e("s_add_u32 s23, s23, 1")
+        e("s_cmp_lg_u32 s23, s28")
+        e("s_cselect_b32 s23, s23, 0")
+        e("s_sub_u32 s35, s28, 1")
+        e("s_cmp_eq_u32 s23, s35")
+        e("s_cselect_b32 s29, s27, s26")
+        e("2:")
+
+    def dma(f, k):
+        if f % 4 != 1:
+            return
+        q = f >> 2
+        if q == 0:
+            e(f"s_mov_b32 m0, s{30 + k}")
+            e("s_nop 0")
+        e(f"global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+        if q == 3:
+            loader_advance()
+
+    def begin_stage():
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+
+    def refill(f, k):
+        base = 10 + k if f < 8 else 10 + ((k + 1) & 3)
+        e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
+
+    # ---------------------------------------------------------------- setup
+    e("s_nop 15")
+    e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
+    e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
+    e("s_mov_b32 s20, %16")
+    e("s_mov_b32 s21, %17")
+    e("s_mov_b32 s22, %18")
+    e("s_mov_b32 s23, %19")
+    e("s_mov_b32 s29, %20")
+    e("s_and_b32 s26, %21, 0x3ff")
+    e("s_bfe_u32 s27, %21, 0xa000a")                         # offset 10, width 10
+    e("s_bfe_u32 s28, %21, 0x80014")                         # offset 20, width 8
+    e("s_mov_b64 s[36:37], %22")
+    e("s_lshl_b32 s35, s21, 14")
+    e("s_add_u32 s24, s36, s35")
+    e("s_addc_u32 s25, s37, 0")
+    if dt == "f16":
+        e("s_mov_b32 s38, 0x7bff7bff")
+    for k in range(4):                                       # stage k of a chunk uses slot (st_slot+1+k)&3; the bias stage = k 3
+        e(f"s_add_u32 s35, s20, {1 + k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"v_add_u32 v{10 + k}, s35, %24")
+        e(f"s_add_u32 s35, s22, {1 + k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"s_add_u32 s{30 + k}, s35, %23")
+    e("v_mov_b32 v14, %26")
+    e("v_mov_b32 v15, %25")
+    e("v_mov_b32 v16, %27")
+    e("v_mov_b32 v17, 0")
+    e("v_mov_b32 v18, 0")
+    e("v_mov_b32 v19, 0")
+    # chunk 0's fc_0.bias rows into the chunk accumulator, then the first 8 fragments of the bias stage
+    for q in range(4):
+        e(f"ds_read_b128 v[{40 + 4 * q}:{43 + 4 * q}], v14 offset:{32 * q}")
+    e("v_add_u32 v14, 0x80, v14")
+    for i in range(8):
+        e(f"ds_read_b128 {A(i)}, v13 offset:{i * 1024}")
+
+    # ---------------------------------------------------------------- snapshot interleaved with the fc_1-bias stage
+    begin_stage()
+    for t in range(16):
+        for s in range(2):
+            for p in range(4):
+                relu_pack(128 + (t * 2 + s) * 4 + p, 16 * t + 8 * s + 2 * p, 16 * t + 8 * s + 2 * p + 1, 68 + 2 * (p & 1))
+        f = t
+        if f % 4 == 0:
+            e("s_waitcnt lgkmcnt(4)")
+        e(f"{mfma} a[{16 * t}:{16 * t + 15}], {A(f & 7)}, v[16:19], a[{16 * t}:{16 * t + 15}]")
+        refill(f, 3)
+        dma(f, 3)
+
+    # ---------------------------------------------------------------- 16 chunks
+    e("s_mov_b32 s34, 16")
+    e("1:")
+    for half in range(2):                                    # fc_0: chunk accumulator v[40:55] += W0[chunk] . relu(x)
+        k = half
+        begin_stage()
+        for f in range(16):
+            if f % 4 == 0:
+                e("s_waitcnt lgkmcnt(4)")                  # (the fc_0.bias loads are older than every fragment load waited for here)
+            e(f"{mfma} v[40:55], {A(f & 7)}, {XB(8 * half + (f >> 1), f & 1)}, v[40:55]")
+            refill(f, k)
+            dma(f, k)
+    begin_stage()                                            # fc_1 stage 0's wait + barrier, under the chain's tail
+    e("s_nop 15")
+    e("s_nop 7")
+    for i in range(8):                                       # relu(h) -> two B fragments
+        e(f"{cvt} v{60 + i}, v{40 + 2 * i}, v{41 + 2 * i}")
+        e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
+        if dt == "f16":
+            e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
+    for q in range(4):                                       # next chunk's fc_0.bias rows
+        e(f"ds_read_b128 v[{40 + 4 * q}:{43 + 4 * q}], v14 offset:{32 * q}")
+    e("v_add_u32 v14, 0x80, v14")
+    for half in range(2):                                    # fc_1: x[tn] += W1[tn, chunk] . relu(h)
+        k = 2 + half
+        if half == 1:
+            begin_stage()
+        for f in range(16):
+            tn = 8 * half + (f >> 1)
+            if f % 4 == 0:
+                # the 4 bias loads issued above are younger than fragments 0..7 of this stage: allow 8 outstanding there
+                e("s_waitcnt lgkmcnt(8)" if (half == 0 and f == 0) else "s_waitcnt lgkmcnt(4)")
+            e(f"{mfma} a[{16 * tn}:{16 * tn + 15}], {A(f & 7)}, v[{60 + 4 * (f & 1)}:{63 + 4 * (f & 1)}], a[{16 * tn}:{16 * tn + 15}]")
+            refill(f, k)
+            dma(f, k)
+    e("s_sub_u32 s34, s34, 1")
+    e("s_cmp_lg_u32 s34, 0")
+    e("s_cbranch_scc1 1b")
+
+    # ---------------------------------------------------------------- exit
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b32 m0, s39")
+    e("s_add_u32 s20, s20, 1")
+    e("s_and_b32 %16, s20, 3")
+    e("s_mov_b32 %17, s21")
+    e("s_add_u32 s22, s22, 1")
+    e("s_and_b32 %18, s22, 3")
+    e("s_mov_b32 %19, s23")
+    e("s_mov_b32 %20, s29")
+    return L
+
+
+def gen_xstages(dt):
+    """n_lds stages 'x[tn] += A_tn . B' with B = the k-step image [k][lane] at LDS address %26 (+1024 per stage, 16 k-steps
+    per 256-channel group -> the caller passes the address of the first k-step), then (cfg2 bit 8) one bias stage.
+    Operands: %0-%15 x tiles, %16-%20 cursor in/out (as the resblock), %21 cfg, %22 stream, %23 ring+wave*4096 (s),
+    %24 ring+lane*16 (v), %25 DMA lane offset (v), %26 B image address (v), %27 bias B dword 0 (v), %28 cfg2 = n_lds | bias<<8."""
+    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
+    L = []
+    e = L.append
+
+    def loader_advance():
+        e("s_add_u32 s21, s21, 1")
+        e("s_add_u32 s24, s24, 0x4000")
+        e("s_addc_u32 s25, s25, 0")
+        e("s_cmp_lg_u32 s21, s29")
+        e("s_cbranch_scc1 2f")
+        e("s_mov_b32 s21, 0")
+        e("s_mov_b64 s[24:25], s[36:37]")
+        e("s_add_u32 s23, s23, 1")
+        e("s_cmp_lg_u32 s23, s28")
+        e("s_cselect_b32 s23, s23, 0")
+        e("s_sub_u32 s35, s28, 1")
+        e("s_cmp_eq_u32 s23, s35")
+        e("s_cselect_b32 s29, s27, s26")
+        e("2:")
+
+    def stage_body(breg):
+        # cur base v10, nxt base v11, M0 value s30, B fragment in v[breg:breg+3]
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+        for f in range(16):
+            if f % 4 == 0:
+                e("s_waitcnt lgkmcnt(4)" if f else "s_waitcnt lgkmcnt(4)")
+            e(f"{mfma} a[{16 * f}:{16 * f + 15}], {A(f & 7)}, v[{breg}:{breg + 3}], a[{16 * f}:{16 * f + 15}]")
+            base = 10 if f < 8 else 11
+            e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
+            if f % 4 == 1:
+                q = f >> 2
+                if q == 0:
+                    e("s_mov_b32 m0, s30")
+                    e("s_nop 0")
+                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                if q == 3:
+                    loader_advance()
+
+    def advance_slots():
+        e("s_add_u32 s20, s20, 1")
+        e("s_and_b32 s20, s20, 3")
+        e("s_add_u32 s22, s22, 1")
+        e("s_and_b32 s22, s22, 3")
+        e("v_mov_b32 v10, v11")                              # cur <- nxt
+        e("s_add_u32 s35, s20, 1")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e("v_add_u32 v11, s35, %24")                          # nxt
+        e("s_lshl_b32 s35, s22, 14")
+        e("s_add_u32 s30, s35, %23")                          # DMA destination of the stage being loaded
+
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b32 s39, m0")
+    e("s_mov_b32 s20, %16")
+    e("s_mov_b32 s21, %17")
+    e("s_mov_b32 s22, %18")
+    e("s_mov_b32 s23, %19")
+    e("s_mov_b32 s29, %20")
+    e("s_and_b32 s26, %21, 0x3ff")
+    e("s_bfe_u32 s27, %21, 0xa000a")
+    e("s_bfe_u32 s28, %21, 0x80014")
+    e("s_mov_b64 s[36:37], %22")
+    e("s_lshl_b32 s35, s21, 14")
+    e("s_add_u32 s24, s36, s35")
+    e("s_addc_u32 s25, s37, 0")
+    e("s_and_b32 s34, %28, 0xff")                            # n_lds
+    e("s_lshl_b32 s35, s20, 14")
+    e("v_add_u32 v10, s35, %24")                              # cur
+    e("s_add_u32 s35, s20, 1")
+    e("s_and_b32 s35, s35, 3")
+    e("s_lshl_b32 s35, s35, 14")
+    e("v_add_u32 v11, s35, %24")                              # nxt
+    e("s_lshl_b32 s35, s22, 14")
+    e("s_add_u32 s30, s35, %23")
+    e("v_mov_b32 v14, %26")
+    e("v_mov_b32 v15, %25")
+    e("ds_read_b128 v[16:19], v14")                           # B of the first k-step
+    e("v_add_u32 v14, 0x400, v14")
+    for i in range(8):
+        e(f"ds_read_b128 {A(i)}, v10 offset:{i * 1024}")
+    e("s_cmp_eq_u32 s34, 0")
+    e("s_cbranch_scc1 3f")
+    e("1:")
+    e("ds_read_b128 v[44:47], v14")                           # next k-step's B (the one past the last is never used)
+    e("v_add_u32 v14, 0x400, v14")
+    stage_body(16)
+    advance_slots()
+    e("s_waitcnt lgkmcnt(8)")                                 # next B landed (8 younger fragment reads may be in flight)
+    e("s_nop 7")                                              # the stage's last MFMAs have read the old B
+    e("v_mov_b32 v16, v44")
+    e("v_mov_b32 v17, v45")
+    e("v_mov_b32 v18, v46")
+    e("v_mov_b32 v19, v47")
+    e("s_sub_u32 s34, s34, 1")
+    e("s_cmp_lg_u32 s34, 0")
+    e("s_cbranch_scc1 1b")
+    e("3:")
+    e("s_bitcmp1_b32 %28, 8")                                 # bias stage requested?
+    e("s_cbranch_scc0 4f")
+    e("v_mov_b32 v16, %27")
+    e("v_mov_b32 v17, 0")
+    e("v_mov_b32 v18, 0")
+    e("v_mov_b32 v19, 0")
+    e("s_nop 1")
+    stage_body(16)
+    advance_slots()
+    e("4:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b32 m0, s39")
+    e("s_mov_b32 %16, s20")
+    e("s_mov_b32 %17, s21")
+    e("s_mov_b32 %18, s22")
+    e("s_mov_b32 %19, s23")
+    e("s_mov_b32 %20, s29")
+    return L
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixel_nerf_multiscale_amd", "csrc", "resblock_asm.inc")
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen_resblock_asm.py — do not edit.  See that file for the register contract.\n")
+        for dt, name, fn in (("bf16", "PNR_RESBLOCK_ASM_BF16", gen), ("f16", "PNR_RESBLOCK_ASM_F16", gen),
+                             ("bf16", "PNR_XSTAGES_ASM_BF16", gen_xstages), ("f16", "PNR_XSTAGES_ASM_F16", gen_xstages)):
+            lines = fn(dt)
+            f.write(f"#define {name} \\\n")
+            for l in lines:
+                f.write(f'    "{l}\\n\\t" \\\n')
+            f.write('    ""\n\n')
+        clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 20)) + list(range(40, 56)) + list(range(60, 72)) + list(range(96, 256))] \
+            + [f"s{i}" for i in range(20, 40)]
+        f.write("#define PNR_RESBLOCK_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+    # audit: every physical v/s register the text names must be declared clobbered (operands are %N references)
+    import re
+    body = open(out).read()
+    body = body[:body.index("#define PNR_RESBLOCK_CLOBBERS")]
+    used = {m.group(1) + m.group(2) for m in re.finditer(r"\b([vs])(\d+)\b", body)}
+    for m in re.finditer(r"\b([vs])\[(\d+):(\d+)\]", body):
+        used |= {m.group(1) + str(i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    stray = sorted(used - set(clob))
+    assert not stray, f"registers used but not clobbered: {stray}"
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
