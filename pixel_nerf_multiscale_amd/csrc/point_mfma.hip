@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     // n_lds k-steps whose B fragment is image [k-step][lane] in this wave's LDS buffer, then n_bias (0/1) bias stages
     auto x_stages = [&](int n_lds, int n_bias, bool use_asm = true) {
 #ifndef PNR_NO_ASM_RESBLOCK
-        if (!MULTIVIEW && use_asm) {
+        if (use_asm) {
             int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
             const int cfg2 = n_lds | (n_bias << 8);
             const uint32_t zaddr = lds_addr(zwave) + lane * 16;
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             STAMP_ACC(3, st_t);
             // ---- resblock: x += fc_1(relu(fc_0(relu(x)))) + biases  (resnetfc.py:53-62)
 #ifndef PNR_NO_ASM_RESBLOCK
-            if constexpr (!MULTIVIEW) {
+            if constexpr (true) {
                 // hand-scheduled block (tools/gen_resblock_asm.py -> resblock_asm.inc): snapshot, fc_1-bias stage, 16 chunks
                 int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
                 const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + h * 16;
@@ -667,43 +667,27 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             ++b;
             // ---- multi-view reduction after the last per-view block (util.combine_interleaved, util.py:466-476)
             if (MULTIVIEW && b == a.nb1 && a.NS > 1) {
-                // pointers are stepped through an opaque asm so that hipcc does not hoist 64+ precomputed addresses
-                // out of the tile loop (they would be spilled around the MFMA loops)
-                float4* pp = a.spill + ((size_t)(blockIdx.x * 4 + wv) * (a.NS - 1)) * 4096 + lane;
+                // Per-view residual streams are parked in the workspace and reduced by the last view.  Both steps are asm
+                // blocks on the pinned accumulator tiles (resblock_asm.inc): element-wise C++ on x made hipcc stage whole
+                // tiles through VGPR tuples, spill them, and (with pinned tiles) emit illegal copies.
+                const float4* slot0 = a.spill + ((size_t)(blockIdx.x * 4 + wv) * (a.NS - 1)) * 4096;
+                const uint32_t lane16 = lane * 16;
+#define PNR_X_TILES                                                                                                     \
+    "+{a[0:15]}"(x[0]), "+{a[16:31]}"(x[1]), "+{a[32:47]}"(x[2]), "+{a[48:63]}"(x[3]), "+{a[64:79]}"(x[4]),               \
+    "+{a[80:95]}"(x[5]), "+{a[96:111]}"(x[6]), "+{a[112:127]}"(x[7]), "+{a[128:143]}"(x[8]), "+{a[144:159]}"(x[9]),      \
+    "+{a[160:175]}"(x[10]), "+{a[176:191]}"(x[11]), "+{a[192:207]}"(x[12]), "+{a[208:223]}"(x[13]),                    \
+    "+{a[224:239]}"(x[14]), "+{a[240:255]}"(x[15])
                 if (v < a.NS - 1) {
-                    pp += (size_t)v * 4096;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            asm volatile("" : "+v"(pp));
-                            *pp = make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
-                            pp += 64;
-                        }
+                    const float4* slot = slot0 + (size_t)v * 4096;
+                    asm volatile(PNR_VIEWSPILL_ASM : PNR_X_TILES : "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
                     ++v; b = 0; start = true;
                     continue;
                 }
+                const int nm1 = a.NS - 1;
                 const float inv = 1.0f / (float)a.NS;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        asm volatile("" : "+v"(pp));
-                        float4 acc = *pp;
-                        for (int u = 1; u < a.NS - 1; ++u) {
-                            float4 o = pp[(size_t)u * 4096];
-                            if (a.combine_max) { acc.x = fmaxf(acc.x, o.x); acc.y = fmaxf(acc.y, o.y); acc.z = fmaxf(acc.z, o.z); acc.w = fmaxf(acc.w, o.w); }
-                            else { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-                        }
-                        pp += 64;
-                        if (a.combine_max) {
-                            x[t][4 * q] = fmaxf(acc.x, x[t][4 * q]); x[t][4 * q + 1] = fmaxf(acc.y, x[t][4 * q + 1]);
-                            x[t][4 * q + 2] = fmaxf(acc.z, x[t][4 * q + 2]); x[t][4 * q + 3] = fmaxf(acc.w, x[t][4 * q + 3]);
-                        } else {
-                            x[t][4 * q] = (acc.x + x[t][4 * q]) * inv; x[t][4 * q + 1] = (acc.y + x[t][4 * q + 1]) * inv;
-                            x[t][4 * q + 2] = (acc.z + x[t][4 * q + 2]) * inv; x[t][4 * q + 3] = (acc.w + x[t][4 * q + 3]) * inv;
-                        }
-                    }
+                asm volatile(PNR_VIEWREDUCE_ASM : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
+                             : PNR_RESBLOCK_CLOBBERS);
+#undef PNR_X_TILES
             }
             if (b == a.n_blocks) break;
         }

@@ -277,13 +277,14 @@ def test_gen_rays_kernel_matches_host():
     assert maxdiff(dev, ref) <= 2e-6
 
 
-@pytest.mark.parametrize("NS,SB,cv", [(2, 2, False), (4, 1, True), (1, 3, False)])
-def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv):
+@pytest.mark.parametrize("NS,SB,cv,comb", [(2, 2, False, "average"), (4, 1, True, "average"), (1, 3, False, "average"),
+                                           (3, 1, False, "max")])
+def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv, comb):
     """Full-width MFMA kernel vs the fp32 HIP path (pinned to the reference by the fixtures, incl. SB=2) on shapes
     the fixtures do not hold at d_hidden=512: several objects per call, 2/4 source views, coded viewdirs."""
     from hip_util import build_net, build_renderer
     import golden_util as gu
-    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=200, use_code_viewdirs=cv, seed=70 + NS + SB)
+    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=200, use_code_viewdirs=cv, seed=70 + NS + SB, combine_type=comb)
     rays_np, poses = gu.make_inputs(spec)
     rays = torch.from_numpy(rays_np).cuda()
     outs = {}

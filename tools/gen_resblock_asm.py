@@ -313,13 +313,93 @@ def gen_xstages(dt):
     return L
 
 
+def gen_viewspill():
+    """Park this view's residual stream: x (16 tiles) -> workspace slot, float4 index (t*4+q)*64 + lane.
+    Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v)."""
+    L = []
+    e = L.append
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b64 s[24:25], %16")
+    for t in range(16):
+        for q in range(4):
+            e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+        e("s_add_u32 s24, s24, 0x1000")
+        e("s_addc_u32 s25, s25, 0")
+    return L
+
+
+def gen_viewreduce():
+    """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max), one pass per parked view, the next tile's 4 loads
+    in flight while a tile is combined.  Operands: %0-%15 x (pinned), %16 slot_0 base (s64), %17 NS-1 (s),
+    %18 combine_max (s), %19 lane*16 (v), %20 1/NS (v)."""
+    L = []
+    e = L.append
+
+    def loads(buf):
+        for q in range(4):
+            e(f"global_load_dwordx4 v[{buf + 4 * q}:{buf + 4 * q + 3}], %19, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+        e("s_add_u32 s24, s24, 0x1000")
+        e("s_addc_u32 s25, s25, 0")
+
+    def combine_pass(op):
+        bufs = (40, 96)
+        loads(bufs[0])
+        for t in range(16):
+            if t < 15:
+                loads(bufs[(t + 1) & 1])
+                e("s_waitcnt vmcnt(4)")
+            else:
+                e("s_waitcnt vmcnt(0)")
+            b = bufs[t & 1]
+            for i in range(16):
+                tmp = 68 + (i & 3)
+                e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
+                e(f"{op} v{tmp}, v{tmp}, v{b + i}")
+                e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
+
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b64 s[26:27], %16")
+    e("s_mov_b32 s34, %17")
+    e("s_cmp_lg_u32 %18, 0")
+    e("s_cbranch_scc1 5f")
+    e("1:")                                                   # ---- sum over parked views, then scale
+    e("s_mov_b64 s[24:25], s[26:27]")
+    combine_pass("v_add_f32")
+    e("s_add_u32 s26, s26, 0x10000")
+    e("s_addc_u32 s27, s27, 0")
+    e("s_sub_u32 s34, s34, 1")
+    e("s_cmp_lg_u32 s34, 0")
+    e("s_cbranch_scc1 1b")
+    for t in range(16):
+        for i in range(16):
+            tmp = 68 + (i & 3)
+            e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
+            e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
+            e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
+    e("s_branch 6f")
+    e("5:")                                                   # ---- max over parked views
+    e("s_mov_b64 s[24:25], s[26:27]")
+    combine_pass("v_max_f32")
+    e("s_add_u32 s26, s26, 0x10000")
+    e("s_addc_u32 s27, s27, 0")
+    e("s_sub_u32 s34, s34, 1")
+    e("s_cmp_lg_u32 s34, 0")
+    e("s_cbranch_scc1 5b")
+    e("6:")
+    e("s_nop 7")
+    return L
+
+
 def main():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixel_nerf_multiscale_amd", "csrc", "resblock_asm.inc")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_resblock_asm.py — do not edit.  See that file for the register contract.\n")
         for dt, name, fn in (("bf16", "PNR_RESBLOCK_ASM_BF16", gen), ("f16", "PNR_RESBLOCK_ASM_F16", gen),
-                             ("bf16", "PNR_XSTAGES_ASM_BF16", gen_xstages), ("f16", "PNR_XSTAGES_ASM_F16", gen_xstages)):
-            lines = fn(dt)
+                             ("bf16", "PNR_XSTAGES_ASM_BF16", gen_xstages), ("f16", "PNR_XSTAGES_ASM_F16", gen_xstages),
+                             (None, "PNR_VIEWSPILL_ASM", gen_viewspill), (None, "PNR_VIEWREDUCE_ASM", gen_viewreduce)):
+            lines = fn(dt) if dt else fn()
             f.write(f"#define {name} \\\n")
             for l in lines:
                 f.write(f'    "{l}\\n\\t" \\\n')
