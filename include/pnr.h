@@ -182,6 +182,56 @@ int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_ml
                    const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
                    const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream);
 
+/* ---- training: the same path under autograd, train/train.py:324-346,382-410 ---------- */
+/* Gradient buffers, shaped like the pnr_mlp weights; every non-NULL member is ACCUMULATED into (+=, fp32
+ * atomics), so the caller zeroes them (or passes .grad tensors).  NULL members are skipped. */
+typedef struct pnr_mlp_grads {
+    float* lin_in_w;  float* lin_in_b;
+    float* lin_z_w[PNR_MAX_BLOCKS];  float* lin_z_b[PNR_MAX_BLOCKS];
+    float* fc0_w[PNR_MAX_BLOCKS];    float* fc0_b[PNR_MAX_BLOCKS];
+    float* fc1_w[PNR_MAX_BLOCKS];    float* fc1_b[PNR_MAX_BLOCKS];
+    float* lin_out_w; float* lin_out_b;
+} pnr_mlp_grads;
+
+/* Saved activations of one pnr_point_mlp_train_fwd call (what autograd would keep for ResnetFC.forward,
+ * resnetfc.py:173-236) and the scratch its backward needs.  fp32 arithmetic, fp32 latent maps required. */
+uint64_t pnr_train_tape_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);
+uint64_t pnr_train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);
+
+/* PixelNeRFNet.forward as pnr_point_mlp (same point naming), keeping the tape. */
+int32_t pnr_point_mlp_train_fwd(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                const float* rays, const float* z, int32_t K,
+                                const float* xyz, const float* viewdirs,
+                                int64_t n_points, int64_t points_per_obj,
+                                float* out, void* tape, uint64_t tape_bytes, void* stream);
+
+/* Backward of the call above: d_out (n_points,4) w.r.t. the activated outputs `out`.
+ *   grads      MLP weight/bias gradients (+=)
+ *   d_latent   per level, same shape as views->latent[level] (+=), or NULL entries / NULL array (encoder frozen,
+ *              PixelNeRFNet.stop_encoder_grad, models.py.backup2:228-229)
+ *   d_xyz      (n_points,3) explicit mode, or d_z (n_rays,K) rays mode: gradient w.r.t. the sample
+ *              positions (needed because nerf.py:287-289 does not detach the depth-guided samples); NULL = skip */
+int32_t pnr_point_mlp_bwd(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                          const float* rays, const float* z, int32_t K,
+                          const float* xyz, const float* viewdirs,
+                          int64_t n_points, int64_t points_per_obj,
+                          const float* out, const float* d_out, void* tape, uint64_t tape_bytes,
+                          const pnr_mlp_grads* grads, float* const* d_latent, float* d_xyz, float* d_z,
+                          void* workspace, uint64_t workspace_bytes, void* stream);
+
+/* Backward of pnr_composite (render/nerf.py:178-182,223-249).  d_weights / d_rgb / d_depth may be NULL (zero);
+ * writes d_rgbsigma (N,K,4) and, when non-NULL, d_z (N,K) (deltas and depth depend on z). */
+int32_t pnr_composite_bwd(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays, int32_t K,
+                          int32_t white_bkgd, const float* d_weights, const float* d_rgb, const float* d_depth,
+                          float* d_rgbsigma, float* d_z, void* stream);
+
+/* Backward of pnr_sample_fine w.r.t. the coarse depth (only the n_fine_depth samples are differentiable):
+ * g / seed / ray_index_base as given to the forward call; z_sorted is its output. */
+int32_t pnr_sample_fine_bwd(const float* rays, const float* depth, int64_t n_rays, int32_t n_coarse,
+                            int32_t n_fine, int32_t n_fine_depth, float depth_std, const float* g,
+                            uint64_t seed, int64_t ray_index_base, const float* z_sorted,
+                            const float* d_z_sorted, float* d_depth, void* stream);
+
 /* util.gen_rays for one camera (util/util.py:118-148,243-281): pixels [pix0, pix0+n) of a W x H pinhole image. */
 int32_t pnr_gen_rays(const float* c2w /* host, 16 floats */, int32_t W, int32_t H, float fx, float fy,
                      float cx, float cy, float z_near, float z_far, int64_t pix0, int64_t n,

@@ -52,6 +52,16 @@ class pnr_params(C.Structure):
     ]
 
 
+class pnr_mlp_grads(C.Structure):
+    _fields_ = [
+        ("lin_in_w", _fp), ("lin_in_b", _fp),
+        ("lin_z_w", _fp * PNR_MAX_BLOCKS), ("lin_z_b", _fp * PNR_MAX_BLOCKS),
+        ("fc0_w", _fp * PNR_MAX_BLOCKS), ("fc0_b", _fp * PNR_MAX_BLOCKS),
+        ("fc1_w", _fp * PNR_MAX_BLOCKS), ("fc1_b", _fp * PNR_MAX_BLOCKS),
+        ("lin_out_w", _fp), ("lin_out_b", _fp),
+    ]
+
+
 class pnr_noise(C.Structure):
     _fields_ = [("noise_c", _fp), ("u", _fp), ("r", _fp), ("g", _fp)]
 
@@ -79,6 +89,15 @@ PROTOTYPES = {
     "pnr_workspace_bytes": (_u64, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_render": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _i64,
                           _i64, C.POINTER(pnr_noise), _u64, _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),
+    "pnr_train_tape_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
+    "pnr_train_bwd_workspace_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
+    "pnr_point_mlp_train_fwd": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _fp, _i32,
+                                       _fp, _fp, _i64, _i64, _fp, _fp, _u64, _fp]),
+    "pnr_point_mlp_bwd": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _fp, _i32, _fp, _fp,
+                                 _i64, _i64, _fp, _fp, _fp, _u64, C.POINTER(pnr_mlp_grads), C.POINTER(C.c_void_p), _fp, _fp,
+                                 _fp, _u64, _fp]),
+    "pnr_composite_bwd": (_i32, [_fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "pnr_sample_fine_bwd": (_i32, [_fp, _fp, _i64, _i32, _i32, _i32, _f, _fp, _u64, _i64, _fp, _fp, _fp, _fp]),
     "pnr_gen_rays": (_i32, [C.POINTER(C.c_float), _i32, _i32, _f, _f, _f, _f, _f, _f, _i64, _i64, _fp, _fp]),
     "pnr_event_create": (_i32, [C.POINTER(C.c_void_p)]),
     "pnr_event_record": (_i32, [_fp, _fp]),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpnr_hip.so")
-SOURCES = ["pnr_api.hip", "stage_kernels.hip", "point_f32.hip", "point_mfma.hip"]
+SOURCES = ["pnr_api.hip", "stage_kernels.hip", "point_f32.hip", "point_mfma.hip", "train_f32.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +24,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, "pnr_common.h"), os.path.join(HERE, "..", "include", "pnr.h")]
-    hdrs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -10,6 +10,15 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
 uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
                    int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+// train_f32.hip
+uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
+uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
+int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
+                        int64_t pts_per_obj, float* out, void* tape, uint64_t tape_bytes, hipStream_t s);
+int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
+                  int64_t pts_per_obj, const float* out, const float* d_out, void* tape, uint64_t tape_bytes,
+                  const pnr_mlp_grads* gr, float* const* d_latent, float* d_xyz, float* d_z, void* workspace,
+                  uint64_t ws_bytes, hipStream_t s);
 }  // namespace pnr
 
 using namespace pnr;
@@ -94,6 +103,67 @@ extern "C" int32_t pnr_point_mlp(const pnr_params* params, const pnr_mlp* mlp, c
     if (!workspace && n_points > 0) return PNR_E_NULL;
     return point_dispatch(params, mlp, views, src, n_points, points_per_obj, out, workspace, workspace_bytes,
                           (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ training entry points (train_f32.hip)
+static int32_t point_args(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views, const float* rays,
+                          const float* z, int32_t K, const float* xyz, const float* viewdirs, int64_t n_points,
+                          int64_t points_per_obj, PointSrc* src) {
+    int32_t rc = check_model(params, mlp, views);
+    if (rc) return rc;
+    for (int i = 0; i < views->n_levels; ++i)
+        if (!views->latent[i]) return PNR_E_NULL;      // the training path reads the fp32 maps
+    *src = PointSrc{};
+    if (rays) {
+        if (!z || K <= 0) return PNR_E_NULL;
+        src->rays = rays; src->z = z; src->K = K;
+        if (n_points % K != 0) return PNR_E_SHAPE;
+    } else {
+        if (!xyz || !viewdirs) return PNR_E_NULL;
+        src->xyz = xyz; src->dirs = viewdirs; src->K = 1;
+    }
+    if (n_points < 0 || points_per_obj <= 0 || n_points != points_per_obj * views->n_objs) return PNR_E_SHAPE;
+    return PNR_OK;
+}
+
+extern "C" uint64_t pnr_train_tape_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points) {
+    if (!mlp || !views || n_points < 0) return 0;
+    return train_tape_bytes(mlp, views, n_points);
+}
+
+extern "C" uint64_t pnr_train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points) {
+    if (!mlp || !views || n_points < 0) return 0;
+    return train_bwd_workspace_bytes(mlp, views, n_points);
+}
+
+extern "C" int32_t pnr_point_mlp_train_fwd(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                           const float* rays, const float* z, int32_t K, const float* xyz,
+                                           const float* viewdirs, int64_t n_points, int64_t points_per_obj,
+                                           float* out, void* tape, uint64_t tape_bytes, void* stream) {
+    PointSrc src;
+    int32_t rc = point_args(params, mlp, views, rays, z, K, xyz, viewdirs, n_points, points_per_obj, &src);
+    if (rc) return rc;
+    if (!out || (!tape && n_points > 0)) return PNR_E_NULL;
+    if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    if (n_points == 0) return PNR_OK;
+    return point_train_fwd(params, mlp, views, src, n_points, points_per_obj, out, tape, tape_bytes, (hipStream_t)stream);
+}
+
+extern "C" int32_t pnr_point_mlp_bwd(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                     const float* rays, const float* z, int32_t K, const float* xyz,
+                                     const float* viewdirs, int64_t n_points, int64_t points_per_obj,
+                                     const float* out, const float* d_out, void* tape, uint64_t tape_bytes,
+                                     const pnr_mlp_grads* grads, float* const* d_latent, float* d_xyz, float* d_z,
+                                     void* workspace, uint64_t workspace_bytes, void* stream) {
+    PointSrc src;
+    int32_t rc = point_args(params, mlp, views, rays, z, K, xyz, viewdirs, n_points, points_per_obj, &src);
+    if (rc) return rc;
+    if (!out || !d_out || !grads || ((!tape || !workspace) && n_points > 0)) return PNR_E_NULL;
+    if ((((uintptr_t)out | (uintptr_t)d_out) & 15) != 0) return PNR_E_ALIGN;
+    if (rays ? d_xyz != nullptr : d_z != nullptr) return PNR_E_SHAPE;   // d_z goes with rays, d_xyz with explicit points
+    if (n_points == 0) return PNR_OK;
+    return point_bwd(params, mlp, views, src, n_points, points_per_obj, out, d_out, tape, tape_bytes, grads, d_latent,
+                     d_xyz, d_z, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 struct RenderWs { uint64_t zc, zf, rgbs, w, rgb, depth, point, total; };

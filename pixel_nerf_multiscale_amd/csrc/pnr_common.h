@@ -144,6 +144,32 @@ __device__ __forceinline__ Taps bilinear_taps(float u, float v, int W, int H) {
     return t;
 }
 
+// Derivatives of the tap weights with respect to the texel coordinate (ATen grid_sampler_2d_backward,
+// align_corners=True, padding_mode=border): d w_i / d ix, d w_i / d iy; zero for out-of-bounds taps and
+// zero altogether along an axis whose coordinate was clipped (clip_coordinates_set_grad: the gradient
+// is dropped for ix <= 0 or ix >= W-1).  d ix / d u = 1 (the two normalisations cancel).
+struct TapsGrad { float dx[4]; float dy[4]; };
+
+__device__ __forceinline__ TapsGrad bilinear_taps_grad(float u, float v, int W, int H) {
+    float gx = (u / (float)(W - 1)) * 2.0f - 1.0f;
+    float gy = (v / (float)(H - 1)) * 2.0f - 1.0f;
+    float rx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
+    float ry = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+    float mx = (rx > 0.0f && rx < (float)(W - 1)) ? 1.0f : 0.0f;
+    float my = (ry > 0.0f && ry < (float)(H - 1)) ? 1.0f : 0.0f;
+    float ix = fminf((float)(W - 1), fmaxf(rx, 0.0f));
+    float iy = fminf((float)(H - 1), fmaxf(ry, 0.0f));
+    float x0 = floorf(ix), y0 = floorf(iy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    bool bx1 = (int)x0 + 1 <= W - 1, by1 = (int)y0 + 1 <= H - 1;
+    TapsGrad t;
+    t.dx[0] = -(y1 - iy) * mx;                      t.dy[0] = -(x1 - ix) * my;
+    t.dx[1] = bx1 ? (y1 - iy) * mx : 0.0f;          t.dy[1] = bx1 ? -(ix - x0) * my : 0.0f;
+    t.dx[2] = by1 ? -(iy - y0) * mx : 0.0f;         t.dy[2] = by1 ? (x1 - ix) * my : 0.0f;
+    t.dx[3] = (bx1 && by1) ? (iy - y0) * mx : 0.0f; t.dy[3] = (bx1 && by1) ? (ix - x0) * my : 0.0f;
+    return t;
+}
+
 // Positional encoding element j (0-based) of PositionalEncoding.forward (code.py:30-46) for input
 // vector x of dimension d (3 or 6): layout [x(d), sin(f0 x)(d), sin(f0 x + pi/2)(d), sin(f1 x)(d), ...].
 __device__ __forceinline__ float posenc_elem(const float* x, int d, int j, float freq_factor) {

@@ -1,0 +1,579 @@
+// Training path: PixelNeRFNet.forward with a tape + its backward, and the backward of
+// the per-ray stages, in fp32.  The reference trains through autograd (train/train.py:324-346,382-410:
+// calc_losses -> renderer(net) with want_weights, loss.backward()); here the same gradients are explicit
+// kernels behind three C entry points that the Python autograd Functions call:
+//   pnr_point_mlp_train_fwd / pnr_point_mlp_bwd   d(out) -> d(MLP weights), d(latent maps), d(z_samp|xyz)
+//   pnr_composite_bwd                             d(weights,rgb,depth) -> d(rgb,sigma), d(z_samp)
+//   pnr_sample_fine_bwd                           d(z_sorted) -> d(coarse depth)   (nerf.py:287-289: the
+//                                                 depth-guided samples are not detached)
+// Layer math (resnetfc.py:53-62,173-236):  x = lin_in(code); per block b: [combine views at
+// b == combine_layer]; xin = x + lin_z_b(z); h = fc_0(relu(xin)); x = xin + fc_1(relu(h));
+// out = lin_out(relu(x)); rgb = sigmoid, sigma = relu.
+#include "f32_kernels.h"
+
+namespace pnr {
+
+// Y[M,N] = R + mask( act(X[M,K]) op(W) + b ),  op(W)[n][k] = TRANS_W ? W[k*ldw+n] : W[n*ldw+k]
+// mask: keep where Mk[m,n] > 0 (the ReLU derivative of a saved pre-activation).  R, Mk, b may be NULL; R may alias Y.
+template <bool RELU_X, bool TRANS_W>
+static __global__ void __launch_bounds__(256) k_gemm_f32(
+    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ b,
+    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* Y, int ldy, int M, int N, int K) {
+    __shared__ float Xs[16][64 + 4];
+    __shared__ float Ws[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int li = tid + i * 256;
+            {
+                int r = li >> 4, kk = li & 15;
+                int m = m0 + r, k = k0 + kk;
+                float xv = (m < M && k < K) ? X[(size_t)m * ldx + k] : 0.f;
+                if (RELU_X) xv = fmaxf(xv, 0.f);
+                Xs[kk][r] = xv;
+            }
+            if (TRANS_W) {
+                int r = li & 63, kk = li >> 6;
+                int n = n0 + r, k = k0 + kk;
+                Ws[kk][r] = (n < N && k < K) ? W[(size_t)k * ldw + n] : 0.f;
+            } else {
+                int r = li >> 4, kk = li & 15;
+                int n = n0 + r, k = k0 + kk;
+                Ws[kk][r] = (n < N && k < K) ? W[(size_t)n * ldw + k] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; wb[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xa[i], wb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float v = acc[i][j];
+            if (b) v += b[n];
+            if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
+            if (R) v += R[(size_t)m * ldr + n];
+            Y[(size_t)m * ldy + n] = v;
+        }
+    }
+}
+
+// dW[N,K] += sum_m dY[m,n] act(X[m,k]) over this block's row range; db[n] += sum_m dY[m,n] (k-tile 0 only).
+// 64x64 output tile, 16 rows per step; partial sums land with fp32 atomics (split over M to fill the chip).
+template <bool RELU_X>
+static __global__ void __launch_bounds__(256) k_grad_w_f32(
+    const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, float* __restrict__ dW, int ldw,
+    float* __restrict__ db, int M, int N, int K, int rows_per_split) {
+    __shared__ float Ys[16][64 + 4];
+    __shared__ float Xs[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int mb = blockIdx.z * rows_per_split;
+    const int me = min(M, mb + rows_per_split);
+    float acc[4][4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int m0 = mb; m0 < me; m0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int li = tid + i * 256;
+            int mm = li >> 6, c = li & 63;
+            int m = m0 + mm;
+            bool ok = m < me;
+            Ys[mm][c] = (ok && n0 + c < N) ? dY[(size_t)m * ldy + n0 + c] : 0.f;
+            float xv = (ok && k0 + c < K) ? X[(size_t)m * ldx + k0 + c] : 0.f;
+            if (RELU_X) xv = fmaxf(xv, 0.f);
+            Xs[mm][c] = xv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            float ya[4], xb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ya[i] = Ys[mm][ty * 4 + i]; xb[i] = Xs[mm][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[i] += ya[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ya[i], xb[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = n0 + ty * 4 + i;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = k0 + tx * 4 + j;
+            if (k < K) atomicAdd(dW + (size_t)n * ldw + k, acc[i][j]);
+        }
+        if (db && blockIdx.y == 0 && tx == 0) atomicAdd(db + n, bsum[i]);
+    }
+}
+
+// d(pre-activation) of the output head: rgb = sigmoid(o) -> y(1-y); sigma = relu(o) -> [y > 0]
+static __global__ void k_out_act_bwd(const float4* __restrict__ out, const float4* __restrict__ d_out, int64_t n,
+                                     float4* __restrict__ d_o4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 y = out[i], g = d_out[i];
+    g.x *= y.x * (1.0f - y.x);
+    g.y *= y.y * (1.0f - y.y);
+    g.z *= y.z * (1.0f - y.z);
+    g.w = (y.w > 0.f) ? g.w : 0.f;
+    d_o4[i] = g;
+}
+
+// backward of util.combine_interleaved (util.py:466-476): mean -> g/NS to every view; max -> g to the
+// (first) arg-max view.  xpre (NS, per_view) is the saved per-view input of the reduction.
+static __global__ void k_combine_bwd(const float* __restrict__ g, const float* __restrict__ xpre, int NS,
+                                     int64_t per_view, int combine_type, float* __restrict__ gv) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_view) return;
+    float gi = g[i];
+    if (combine_type == PNR_COMBINE_MAX) {
+        int best = 0;
+        float bv = xpre[i];
+        for (int v = 1; v < NS; ++v) {
+            float a = xpre[i + v * per_view];
+            if (a > bv) { bv = a; best = v; }
+        }
+        for (int v = 0; v < NS; ++v) gv[i + v * per_view] = (v == best) ? gi : 0.f;
+    } else {
+        float s = gi / (float)NS;
+        for (int v = 0; v < NS; ++v) gv[i + v * per_view] = s;
+    }
+}
+
+// backward of the feature build (k_features_f32): one wave per point, views in sequence.
+//   d_latent[level][view][c][tap] += dzx[row][c] * w_tap                       (encoder.py:182,198 grid_sample)
+//   d(point) through the projection (backup2:215-221) and the positional code (code.py:30-46)
+// dzx rows are view-major (row = v*P + g).  d_lat entries may be NULL (encoder frozen); d_xyz / d_z may be NULL.
+struct LatGrad { float* p[PNR_MAX_LEVELS]; };
+
+static __global__ void __launch_bounds__(256) k_features_bwd(
+    pnr_views vw, PointSrc src, int64_t P, int64_t pts_per_obj, int L, int d_in, int use_code_viewdirs,
+    int num_freqs, float freq_factor, const float* __restrict__ dzx, LatGrad dl, float* __restrict__ d_xyz,
+    float* __restrict__ d_z) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= P) return;
+    const int E = L + d_in;
+    const bool want_p = (d_xyz != nullptr) || (d_z != nullptr);
+    float p[3], d[3];
+    fetch_point(src, g, p, d);
+    const int obj = (int)(g / pts_per_obj);
+    float dp[3] = {0.f, 0.f, 0.f};
+    for (int v = 0; v < vw.n_views; ++v) {
+        const int view = obj * vw.n_views + v;
+        Cam cam = load_cam(vw, view);
+        float xr[3];
+        rot3(cam.R, p, xr);
+        float u, w;
+        project(cam, xr, u, w);
+        const float* drow = dzx + ((size_t)v * P + g) * E;
+        float du = 0.f, dv = 0.f;
+        int c0 = 0;
+        for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
+            const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
+            Taps t = bilinear_taps(u, w, W, H);
+            TapsGrad tg = bilinear_taps_grad(u, w, W, H);
+            for (int ch = lane; ch < C; ch += 64) {
+                float gz = drow[c0 + ch];
+                size_t base = ((size_t)view * C + ch) * (size_t)(H * W);
+                if (dl.p[lvl]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (t.w[i] != 0.f) atomicAdd(dl.p[lvl] + base + t.off[i], gz * t.w[i]);
+                }
+                if (want_p) {
+                    const float* lb = vw.latent[lvl] + base;
+                    float sx = 0.f, sy = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float val = lb[t.off[i]];
+                        sx += val * tg.dx[i];
+                        sy += val * tg.dy[i];
+                    }
+                    du += gz * sx;
+                    dv += gz * sy;
+                }
+            }
+            c0 += C;
+        }
+        if (!want_p) continue;
+        // positional code: lanes over the code entries, partial d(x_rot) per lane
+        float dxr[3] = {0.f, 0.f, 0.f};
+        const int dd = use_code_viewdirs ? 6 : 3;
+        const int dcode = dd + 2 * num_freqs * dd;        // entries produced by the code
+        for (int j = lane; j < dcode; j += 64) {
+            float gc = drow[L + j];
+            int i;
+            float dv_dx;
+            if (j < dd) { i = j; dv_dx = 1.0f; }
+            else {
+                int q = (j - dd) / dd;
+                i = (j - dd) % dd;
+                float f = freq_factor * (float)(1 << (q >> 1));
+                float ph = (q & 1) ? 1.57079637050628662109375f : 0.0f;
+                dv_dx = (i < 3) ? f * cosf(fmaf(xr[i], f, ph)) : 0.f;
+            }
+            if (i < 3) dxr[i] += gc * dv_dx;
+        }
+        du = wave_sum(du); dv = wave_sum(dv);
+        dxr[0] = wave_sum(dxr[0]); dxr[1] = wave_sum(dxr[1]); dxr[2] = wave_sum(dxr[2]);
+        float xc = xr[0] + cam.t[0], yc = xr[1] + cam.t[1], zc = xr[2] + cam.t[2];
+        dxr[0] += du * (-cam.fx / zc);
+        dxr[1] += dv * (-cam.fy / zc);
+        dxr[2] += du * (xc * cam.fx / (zc * zc)) + dv * (yc * cam.fy / (zc * zc));
+        // p = R^T x_rot
+        dp[0] += cam.R[0] * dxr[0] + cam.R[3] * dxr[1] + cam.R[6] * dxr[2];
+        dp[1] += cam.R[1] * dxr[0] + cam.R[4] * dxr[1] + cam.R[7] * dxr[2];
+        dp[2] += cam.R[2] * dxr[0] + cam.R[5] * dxr[1] + cam.R[8] * dxr[2];
+    }
+    if (lane == 0) {
+        if (d_xyz) { d_xyz[g * 3 + 0] = dp[0]; d_xyz[g * 3 + 1] = dp[1]; d_xyz[g * 3 + 2] = dp[2]; }
+        if (d_z) d_z[g] = dp[0] * d[0] + dp[1] * d[1] + dp[2] * d[2];
+    }
+}
+
+// ------------------------------------------------------------------ composite backward (nerf.py:178-182,223-249)
+// One wave per ray, samples walked from the far end so the suffix sum S_k = sum_{j>k} G_j w_j is a running
+// carry:  G_k = dL/dw_k = gw_k + g_rgb.c_k + g_depth z_k - [white] sum(g_rgb);
+//         dL/dalpha_k = G_k T_k - S_k / (1 - alpha_k + 1e-10);   alpha = 1 - exp(-delta relu(sigma)).
+static __global__ void __launch_bounds__(256) k_composite_bwd(
+    const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ rgbs, int64_t n_rays,
+    int K, int white_bkgd, const float* __restrict__ g_w, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_depth, float4* __restrict__ d_rgbs, float* __restrict__ d_z) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (ray >= n_rays) return;
+    float* Tk = smem + (size_t)wv * 3 * K;       // exclusive transmittance
+    float* dD = Tk + K;                           // d(delta_k)
+    float* dZ = dD + K;                           // direct term of depth = sum w z
+    const float far = rays[ray * 8 + 7];
+    const float* zr = z + ray * K;
+    const float4* cr = rgbs + ray * K;
+    // forward transmittance, as k_composite
+    float carry = 1.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        int k = k0 + lane;
+        bool act = k < K;
+        float zk = act ? zr[k] : 0.f;
+        float zn = (k + 1 < K) ? zr[k + 1] : far;
+        float sg = act ? fmaxf(cr[k].w, 0.0f) : 0.f;
+        float alpha = act ? 1.0f - expf(-(zn - zk) * sg) : 0.0f;
+        float tr = act ? (1.0f - alpha) + 1e-10f : 1.0f;
+        float incl = wave_scan_mul(tr, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (act) Tk[k] = carry * excl;
+        carry *= __shfl(incl, 63, 64);
+    }
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
+    const float gbg = white_bkgd ? (gr + gg + gb) : 0.f;
+    float suffix = 0.f;                           // S for the highest k of the current segment
+    const int nseg = (K + 63) / 64;
+    for (int sgm = nseg - 1; sgm >= 0; --sgm) {
+        int k = sgm * 64 + (63 - lane);           // lane 0 holds the farthest sample of the segment
+        bool act = k < K;
+        float zk = act ? zr[k] : 0.f;
+        float zn = (k + 1 < K) ? zr[k + 1] : far;
+        float4 c = act ? cr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float delta = zn - zk;
+        float sg = fmaxf(c.w, 0.0f);
+        float e = expf(-delta * sg);
+        float alpha = act ? 1.0f - e : 0.f;
+        float T = act ? Tk[k] : 0.f;
+        float w = alpha * T;
+        float G = (g_w ? (act ? g_w[ray * K + k] : 0.f) : 0.f) + gr * c.x + gg * c.y + gb * c.z + gd * zk - gbg;
+        float gwk = act ? G * w : 0.f;
+        float incl = wave_scan_add(gwk, lane);    // inclusive over farther-or-equal samples of this segment
+        float S = suffix + incl - gwk;            // strictly farther samples
+        suffix += __shfl(incl, 63, 64);
+        float dalpha = G * T - S / ((1.0f - alpha) + 1e-10f);
+        float dsig = (c.w > 0.f) ? dalpha * delta * e : 0.f;
+        float ddel = dalpha * sg * e;
+        if (act) {
+            d_rgbs[ray * K + k] = make_float4(w * gr, w * gg, w * gb, dsig);
+            dD[k] = ddel;
+            dZ[k] = w * gd;
+        }
+    }
+    if (d_z) {
+        __builtin_amdgcn_wave_barrier();
+        // delta_k = z_{k+1} - z_k (k < K-1), delta_{K-1} = far - z_{K-1}
+        for (int k = lane; k < K; k += 64)
+            d_z[ray * K + k] = dZ[k] - dD[k] + ((k > 0) ? dD[k - 1] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------ depth-guided samples backward (nerf.py:150-161,287-295)
+// z_d = clamp(depth + g*std, near, far) is differentiable in depth; after cat + sort the sample sits at the
+// slot holding its value.  d(depth) = sum over unclamped depth samples of d(z_sorted) at that slot.
+static __global__ void __launch_bounds__(256) k_sample_fine_bwd(
+    const float* __restrict__ rays, const float* __restrict__ depth, int64_t n_rays, int Kt, int n_dep,
+    float depth_std, const float* __restrict__ gn, uint64_t seed, int64_t ray_base,
+    const float* __restrict__ z_sorted, const float* __restrict__ d_z_sorted, float* __restrict__ d_depth) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+    const float dpt = depth[ray];
+    const float* zs = z_sorted + ray * Kt;
+    const float* gz = d_z_sorted + ray * Kt;
+    float acc = 0.f;
+    for (int j = lane; j < n_dep; j += 64) {
+        float g = gn ? gn[ray * n_dep + j] : rng_normal(seed, ray_base + ray, DRAW_G, j);
+        float zz = dpt + g * depth_std;
+        if (!(zz < far) || !(zz > near)) continue;        // clamped: torch.min / torch.max route the gradient to the bound
+        // first slot holding zz (ascending row): lower bound
+        int lo = 0, hi = Kt;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (zs[mid] < zz) lo = mid + 1; else hi = mid;
+        }
+        // equal values among the depth samples of one ray occupy consecutive slots: rank among equal earlier samples
+        int rank = 0;
+        for (int jj = 0; jj < j; ++jj) {
+            float g2 = gn ? gn[ray * n_dep + jj] : rng_normal(seed, ray_base + ray, DRAW_G, jj);
+            float z2 = dpt + g2 * depth_std;
+            rank += (z2 == zz) ? 1 : 0;
+        }
+        int slot = lo + rank;
+        if (slot < Kt && zs[slot] == zz) acc += gz[slot];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) d_depth[ray] = acc;
+}
+
+// ------------------------------------------------------------------ host side
+struct Tape {
+    float* zx;                       // (NS*P, E)
+    float* A[PNR_MAX_BLOCKS + 1];    // block inputs after lin_z; A[n_blocks] = input of lin_out
+    float* h[PNR_MAX_BLOCKS];        // fc_0 outputs (pre-activation)
+    float* xpre;                     // (NS*P, H) per-view stream entering the view reduction (NS > 1)
+    float* o4;                       // (P, 4) head pre-activations
+    int64_t rows[PNR_MAX_BLOCKS + 1];
+    uint64_t total;
+};
+
+static inline uint64_t a256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
+
+static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void* base) {
+    Tape t{};
+    const int NS = vw->n_views, H = mlp->d_hidden, E = mlp->d_latent + mlp->d_in;
+    uint8_t* p = (uint8_t*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
+    uint64_t off = 0;
+    auto take = [&](uint64_t floats) { float* r = (float*)(p + off); off += a256(floats * 4); return r; };
+    t.zx = take((uint64_t)NS * P * E);
+    for (int b = 0; b <= mlp->n_blocks; ++b) {
+        t.rows[b] = (NS > 1 && b >= mlp->combine_layer) ? P : (int64_t)NS * P;
+        t.A[b] = take((uint64_t)t.rows[b] * H);
+        if (b < mlp->n_blocks) t.h[b] = take((uint64_t)t.rows[b] * H);
+    }
+    t.xpre = NS > 1 ? take((uint64_t)NS * P * H) : nullptr;
+    t.o4 = take((uint64_t)P * 4);
+    t.total = off + 256;
+    return t;
+}
+
+uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
+    return carve_tape(mlp, vw, P, nullptr).total;
+}
+
+uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
+    const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = mlp->d_latent + mlp->d_in;
+    return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + 256;
+}
+
+template <bool RELU_X, bool TRANS_W>
+static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
+                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
+    if (M == 0) return PNR_OK;
+    dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
+    hipLaunchKernelGGL((k_gemm_f32<RELU_X, TRANS_W>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr, Mk, ldm, Y,
+                       ldy, (int)M, N, K);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+template <bool RELU_X>
+static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
+                      int N, int K, hipStream_t s) {
+    if (!dW || M == 0) return PNR_OK;
+    const int rows = 2048;
+    dim3 grid((N + 63) / 64, (K + 63) / 64, (unsigned)((M + rows - 1) / rows));
+    hipLaunchKernelGGL((k_grad_w_f32<RELU_X>), grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, (int)M, N, K, rows);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+#define PNR_TRY(expr) do { int32_t _rc = (expr); if (_rc) return _rc; } while (0)
+
+int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
+                        int64_t pts_per_obj, float* out, void* tape, uint64_t tape_bytes, hipStream_t s) {
+    if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden, E = L + Din;
+    const int nb = mlp->n_blocks, cl = mlp->combine_layer;
+    if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
+    if ((int64_t)NS * P * E > 0x7fffffffLL * 64) return PNR_E_SHAPE;
+    Tape t = carve_tape(mlp, vw, P, tape);
+    const int n_lin_z = cl < nb ? cl : nb;
+    const int64_t MV = (int64_t)NS * P;
+    if (MV > 0x7fffffff) return PNR_E_SHAPE;
+    int64_t tot = MV * E;
+    hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
+                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx);
+    PNR_LAUNCH_CHECK();
+    const bool comb0 = NS > 1 && cl == 0;
+    float* x0 = comb0 ? t.xpre : t.A[0];
+    PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, x0, H, MV, H, Din, s)));
+    auto combine = [&](float* dst) -> int32_t {
+        int64_t per_view = P * H;
+        hipLaunchKernelGGL(k_combine_f32, dim3((unsigned)((per_view + 255) / 256)), dim3(256), 0, s, t.xpre, NS,
+                           per_view, mlp->combine_type, dst);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    };
+    if (comb0) PNR_TRY(combine(t.A[0]));
+    for (int b = 0; b < nb; ++b) {
+        const int64_t M = t.rows[b];
+        if (L > 0 && b < n_lin_z)
+            PNR_TRY((gemm<false, false>(t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], t.A[b], H, nullptr, 0, t.A[b], H, M, H, L, s)));
+        PNR_TRY((gemm<true, false>(t.A[b], H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0, nullptr, 0, t.h[b], H, M, H, H, s)));
+        const bool comb = NS > 1 && b + 1 == cl;
+        float* dst = comb ? t.xpre : t.A[b + 1];
+        PNR_TRY((gemm<true, false>(t.h[b], H, mlp->fc1_w[b], H, mlp->fc1_b[b], t.A[b], H, nullptr, 0, dst, H, M, H, H, s)));
+        if (comb) PNR_TRY(combine(t.A[b + 1]));
+    }
+    PNR_TRY((gemm<true, false>(t.A[nb], H, mlp->lin_out_w, H, mlp->lin_out_b, nullptr, 0, nullptr, 0, t.o4, 4, P, 4, H, s)));
+    hipLaunchKernelGGL(k_out_act, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, t.o4, P, out);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
+                  int64_t pts_per_obj, const float* out, const float* d_out, void* tape, uint64_t tape_bytes,
+                  const pnr_mlp_grads* gr, float* const* d_latent, float* d_xyz, float* d_z, void* workspace,
+                  uint64_t ws_bytes, hipStream_t s) {
+    if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
+    if (ws_bytes < train_bwd_workspace_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden, E = L + Din;
+    const int nb = mlp->n_blocks, cl = mlp->combine_layer;
+    if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
+    Tape t = carve_tape(mlp, vw, P, tape);
+    const int n_lin_z = cl < nb ? cl : nb;
+    const int64_t MV = (int64_t)NS * P;
+    uint8_t* wp = (uint8_t*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* dx = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
+    float* dx2 = (float*)wp;               wp += a256((uint64_t)MV * H * 4);
+    float* dh = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
+    float* dzx = (float*)wp;               wp += a256((uint64_t)MV * E * 4);
+    float* do4 = (float*)wp;
+    const bool want_p = d_xyz || d_z;
+    bool want_lat = false;
+    LatGrad lg{};
+    for (int l = 0; l < vw->n_levels; ++l) { lg.p[l] = d_latent ? d_latent[l] : nullptr; want_lat |= lg.p[l] != nullptr; }
+    const bool want_dz = L > 0 && (want_lat || want_p);
+
+    hipLaunchKernelGGL(k_out_act_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (const float4*)out,
+                       (const float4*)d_out, P, (float4*)do4);
+    PNR_LAUNCH_CHECK();
+    PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s)));
+    PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s)));
+    bool dz_started = false;
+    for (int b = nb - 1; b >= 0; --b) {
+        const int64_t M = t.rows[b];
+        PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s)));
+        PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s)));
+        PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s)));
+        PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s)));
+        if (L > 0 && b < n_lin_z) {
+            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s)));
+            if (want_dz) {
+                PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
+                                           dzx, E, M, L, H, s)));
+                dz_started = true;
+            }
+        }
+        if (NS > 1 && b == cl) {
+            int64_t per_view = P * H;
+            hipLaunchKernelGGL(k_combine_bwd, dim3((unsigned)((per_view + 255) / 256)), dim3(256), 0, s, dx, t.xpre, NS,
+                               per_view, mlp->combine_type, dx2);
+            PNR_LAUNCH_CHECK();
+            float* tmp = dx; dx = dx2; dx2 = tmp;
+        }
+    }
+    PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s)));
+    if ((want_p || want_lat) && L > 0 && !dz_started) PNR_HIP_CHECK(hipMemsetAsync(dzx, 0, (size_t)MV * E * 4, s));
+    if (want_p)
+        PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s)));
+    if (want_p || (want_lat && L > 0)) {
+        hipLaunchKernelGGL(k_features_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, *vw, src, P, pts_per_obj, L, Din,
+                           prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, lg, d_xyz, d_z);
+        PNR_LAUNCH_CHECK();
+    }
+    return PNR_OK;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" int32_t pnr_composite_bwd(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays,
+                                     int32_t K, int32_t white_bkgd, const float* d_weights, const float* d_rgb,
+                                     const float* d_depth, float* d_rgbsigma, float* d_z, void* stream) {
+    if (!rays || !z || !rgbsigma || !d_rgbsigma) return PNR_E_NULL;
+    if (n_rays < 0 || K <= 0) return PNR_E_SHAPE;
+    if ((((uintptr_t)rgbsigma | (uintptr_t)d_rgbsigma) & 15) != 0) return PNR_E_ALIGN;
+    if (n_rays == 0) return PNR_OK;
+    size_t lds = (size_t)4 * 3 * K * sizeof(float);
+    if (lds > 64 * 1024) return PNR_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, (hipStream_t)stream, rays, z,
+                       (const float4*)rgbsigma, n_rays, K, white_bkgd, d_weights, d_rgb, d_depth, (float4*)d_rgbsigma, d_z);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
+extern "C" int32_t pnr_sample_fine_bwd(const float* rays, const float* depth, int64_t n_rays, int32_t n_coarse,
+                                       int32_t n_fine, int32_t n_fine_depth, float depth_std, const float* g,
+                                       uint64_t seed, int64_t ray_index_base, const float* z_sorted,
+                                       const float* d_z_sorted, float* d_depth, void* stream) {
+    if (!rays || !depth || !z_sorted || !d_z_sorted || !d_depth) return PNR_E_NULL;
+    if (n_rays < 0 || n_coarse <= 0 || n_fine < 0 || n_fine_depth < 0 || n_fine_depth > n_fine) return PNR_E_SHAPE;
+    if (n_rays == 0) return PNR_OK;
+    hipLaunchKernelGGL(k_sample_fine_bwd, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rays,
+                       depth, n_rays, n_coarse + n_fine, n_fine_depth, depth_std, g, seed, ray_index_base, z_sorted,
+                       d_z_sorted, d_depth);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}

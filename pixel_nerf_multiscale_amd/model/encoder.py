@@ -99,8 +99,10 @@ class SpatialEncoder(nn.Module):
         return self.latents if self.use_multi_scale else self.latent
 
     def set_latents(self, maps):
-        """Install latent map(s) (list of (SB*NS, C, H, W)) — what forward() leaves on the module."""
-        maps = [m.detach().float().contiguous() for m in maps]
+        """Install latent map(s) (list of (SB*NS, C, H, W)) — what forward() leaves on the module.  Maps that
+        carry an autograd graph (training the trunk, train/train.py:324-346) stay attached to it."""
+        keep_graph = torch.is_grad_enabled() and any(m.requires_grad for m in maps)
+        maps = [(m if keep_graph else m.detach()).float().contiguous() for m in maps]
         self.latents = maps if self.use_multi_scale else []
         self.latent = maps[-1]
         self._level_maps = maps

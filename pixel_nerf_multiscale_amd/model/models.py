@@ -74,6 +74,7 @@ class PixelNeRFNet(torch.nn.Module):
         # arithmetic of the fc layers: "auto" = fp16 MFMA kernel (fp32 accumulate, saturating activations; same speed as
         # bf16 and ~18 dB closer to the fp32 reference) when the shape allows, else the fp32 HIP path
         self.precision = conf.get_string("precision", os.environ.get("PNR_PRECISION", "auto"))
+        self.differentiable = None      # None: follow self.training; True/False: force the taped fp32 path on/off
         self._pack_cache = {}
         self._ws = None
 
@@ -183,24 +184,7 @@ class PixelNeRFNet(torch.nn.Module):
     def views_struct(self, precision):
         maps = self.encoder.level_maps()
         dev = maps[0].device
-        v = N.pnr_views()
-        keep = []
-        nv = maps[0].shape[0]
-        v.n_views = int(self.num_views_per_obj)
-        v.n_objs = nv // v.n_views
-        for name in ("poses", "focal", "c"):
-            t = N.f32c(getattr(self, name), dev)
-            keep.append(t)
-            setattr(v, {"poses": "w2c"}.get(name, name), N.ptr(t))
-        if self.poses.shape[0] != nv:
-            raise ValueError(f"{self.poses.shape[0]} cameras but {nv} latent maps")
-        v.n_focal, v.n_c = self.focal.shape[0], self.c.shape[0]
-        v.n_levels = len(maps)
-        for i, mp in enumerate(maps):
-            mp = N.f32c(mp)
-            keep.append(mp)
-            v.latent[i] = N.ptr(mp)
-            v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+        v, keep = views_from(self.poses, self.focal, self.c, self.num_views_per_obj, maps)
         if precision != "fp32":
             tdt = torch.float16 if precision in ("fp16", "f16") else torch.bfloat16
             maps16 = self.encoder.level_maps16(tdt)
@@ -229,6 +213,31 @@ class PixelNeRFNet(torch.nn.Module):
             v.packed_dtype = N.PRECISIONS[precision]
         return v, keep
 
+    def wants_grad(self, *inputs):
+        """True when the call must go through the differentiable (fp32, taped) path: the module is in training
+        mode (or `differentiable` is forced True), autograd is on, and a parameter, a latent map or one of `inputs`
+        requires grad.  Everything else — eval(), torch.no_grad() — takes the fused inference kernels."""
+        if self.differentiable is not None:
+            if not self.differentiable:
+                return False
+        elif not self.training:
+            return False
+        if not torch.is_grad_enabled():
+            return False
+        if any(t is not None and t.requires_grad for t in inputs):
+            return True
+        if any(p.requires_grad for p in self.mlp_coarse.parameters()):
+            return True
+        if self.mlp_fine is not None and any(p.requires_grad for p in self.mlp_fine.parameters()):
+            return True
+        return any(m.requires_grad for m in self.latent_maps_for_grad())
+
+    def latent_maps_for_grad(self):
+        """Latent maps as autograd sees them: attached to the encoder graph unless stop_encoder_grad
+        (models.py.backup2:228-229)."""
+        maps = self.encoder.level_maps()
+        return [m.detach() for m in maps] if self.stop_encoder_grad else maps
+
     def workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -237,11 +246,12 @@ class PixelNeRFNet(torch.nn.Module):
     # ------------------------------------------------------------------ per-point evaluation (backup2:155-282)
     def forward(self, xyz, coarse=True, viewdirs=None, far=False):
         """xyz (SB, B, 3) world points [, viewdirs (SB, B, 3)] -> (SB, B, 4) = sigmoid(rgb), relu(sigma)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and xyz.requires_grad:
-            raise NotImplementedError("backward through the HIP render path is not implemented (SURVEY N4)")
         assert viewdirs is not None, "use_viewdirs is on: viewdirs required"
         SB, B, _ = xyz.shape
         mlp = self.mlp_coarse if (coarse or self.mlp_fine is None) else self.mlp_fine
+        if self.wants_grad(xyz):
+            from ..render.autograd import point_mlp_points
+            return point_mlp_points(self, mlp, xyz, viewdirs.reshape(SB, B, 3))
         prec = self.resolved_precision(mlp)
         dev = xyz.device
         xyz_c, vd_c = N.f32c(xyz), N.f32c(viewdirs.reshape(SB, B, 3))
@@ -281,6 +291,41 @@ class PixelNeRFNet(torch.nn.Module):
             copyfile(ckpt_path, osp.join(args.checkpoints_path, args.name, backup_name))
         torch.save(self.state_dict(), ckpt_path)
         return self
+
+
+def views_from(poses, focal, c, num_views_per_obj, maps):
+    """pnr_views over explicit camera tensors (as encode() leaves them) and fp32 latent maps."""
+    dev = maps[0].device
+    v = N.pnr_views()
+    keep = []
+    nv = maps[0].shape[0]
+    v.n_views = int(num_views_per_obj)
+    v.n_objs = nv // v.n_views
+    for name, t in (("w2c", poses), ("focal", focal), ("c", c)):
+        t = N.f32c(t.detach(), dev)
+        keep.append(t)
+        setattr(v, name, N.ptr(t))
+    if poses.shape[0] != nv:
+        raise ValueError(f"{poses.shape[0]} cameras but {nv} latent maps")
+    v.n_focal, v.n_c = focal.shape[0], c.shape[0]
+    v.n_levels = len(maps)
+    for i, mp in enumerate(maps):
+        mp = N.f32c(mp.detach())
+        keep.append(mp)
+        v.latent[i] = N.ptr(mp)
+        v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+    return v, keep
+
+
+def mlp_tensors(mlp):
+    """The MLP parameters in a fixed order (autograd inputs of the training Functions)."""
+    ts = [mlp.lin_in.weight, mlp.lin_in.bias, mlp.lin_out.weight, mlp.lin_out.bias]
+    for blk in mlp.blocks:
+        ts += [blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias]
+    if mlp.d_latent:
+        for lz in mlp.lin_z:
+            ts += [lz.weight, lz.bias]
+    return ts
 
 
 def mfma_supported(mlp, net):

@@ -135,11 +135,16 @@ class NeRFRenderer(torch.nn.Module):
         assert len(rays.shape) == 3
         if not rays.is_cuda:
             raise RuntimeError("NeRFRenderer runs on the HIP device only: move rays (and the model) to cuda")
-        if self.training and self.noise_std > 0.0:
-            raise NotImplementedError("sigma noise (training only, nerf.py:225-226) is not implemented")
         from ..model.models import PixelNeRFNet
         if isinstance(model, PixelNeRFNet):
+            if model.wants_grad(rays):
+                from .autograd import render_train          # taped fp32 path + explicit backward kernels (N4)
+                return render_train(self, model, rays, want_weights)
+            if self.training and self.noise_std > 0.0:
+                raise NotImplementedError("sigma noise (nerf.py:225-226) exists on the differentiable path only")
             return self._forward_fused(model, rays, want_weights)
+        if self.training and self.noise_std > 0.0:
+            raise NotImplementedError("sigma noise (nerf.py:225-226) exists on the differentiable path only")
         return self._forward_generic(model, rays, want_weights)
 
     def _forward_fused(self, net, rays, want_weights):

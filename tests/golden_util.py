@@ -166,6 +166,40 @@ def make_latents(spec):
     return [np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) for c, h, w in spec["lat"]]
 
 
+# ----------------------------------------------------------------------------- backward cases
+GRAD_CASES = ["tiny_ns1", "tiny_ns2_lindisp_black", "tiny_ns2_codeview", "tiny_multiscale_ns2", "tiny_sb2_ns2",
+              "tiny_nodepth", "tiny_onlydepth", "tiny_nofine_mlp", "tiny_max_combine", "tiny_ns1_coarse_only",
+              "full_ns1", "full_ns3", "full_multiscale_ns2"]
+GRAD_SAMPLES = 512      # entries kept per gradient tensor larger than this
+
+
+def make_loss_weights(spec):
+    """Seeded cotangents: loss = sum over passes of <rgb, G_rgb> + <depth, G_depth> + <weights, G_weights>
+    (what train/train.py's rgb losses reduce to for one backward, plus depth/weights terms so every output of
+    the renderer carries gradient)."""
+    rng = np.random.default_rng(spec["seed"] * 1000 + 5)
+    SB, N, Kc, Kf = spec["SB"], spec["N"], spec["Kc"], spec["Kf"]
+    g = {}
+    for tag, K in (("coarse", Kc), ("fine", Kc + Kf)):
+        g[f"{tag}_rgb"] = rng.standard_normal((SB, N, 3)).astype(np.float32)
+        g[f"{tag}_depth"] = rng.standard_normal((SB, N)).astype(np.float32)
+        g[f"{tag}_weights"] = rng.standard_normal((SB, N, K)).astype(np.float32)
+    return g
+
+
+def grad_sample_index(key, numel):
+    """Flat indices of the entries of gradient tensor `key` a fixture keeps (all of them when small)."""
+    if numel <= GRAD_SAMPLES:
+        return np.arange(numel)
+    h = int.from_bytes(key.encode(), "little") % (2 ** 31)
+    return np.sort(np.random.default_rng(h).choice(numel, size=GRAD_SAMPLES, replace=False))
+
+
+def load_grad_fixture(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + "_grad.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
 # ----------------------------------------------------------------------------- fixtures
 def fixture_path(name):
     return os.path.join(GOLDEN_DIR, name + ".npz")

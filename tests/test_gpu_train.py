@@ -1,0 +1,163 @@
+"""N4 (SURVEY §8 f): the renderer under autograd — taped fp32 forward + explicit HIP backward kernels
+(csrc/train_f32.hip) through the C ABI — against the REFERENCE's gradients (tests/golden/*_grad.npz, written
+by tools/gen_golden_grad.py) and against the oracle under torch autograd.  Tolerance: fp32 arithmetic with a
+different summation order (tiled GEMMs, atomics): 5e-4 of each tensor's scale."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import hip_util as hu
+from test_oracle_grad import compare_grads, oracle_grads
+
+pytestmark = pytest.mark.gpu
+RTOL = 5e-4
+
+
+def hip_grads(name, fx=None):
+    fx, spec, net, rend = hu.setup(name)
+    net.train()
+    maps = [torch.from_numpy(x).cuda().requires_grad_(True) for x in gu.make_latents(spec)]
+    net.encoder.set_latents(maps)
+    leaf_maps = net.encoder.level_maps()
+    for m in leaf_maps:
+        assert m.requires_grad
+    rays = torch.from_numpy(fx["rays"]).cuda()
+    out = rend(net, rays, want_weights=True)
+    G = {k: torch.from_numpy(v).cuda() for k, v in gu.make_loss_weights(spec).items()}
+    loss = 0.0
+    for tag in ("coarse", "fine") if spec["Kf"] > 0 else ("coarse",):
+        lvl = out[tag]
+        loss = loss + (lvl.rgb * G[f"{tag}_rgb"]).sum() + (lvl.depth * G[f"{tag}_depth"]).sum() \
+            + (lvl.weights * G[f"{tag}_weights"]).sum()
+    loss.backward()
+    grads = {}
+    for which, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)):
+        if mlp is not None:
+            for k, p in mlp.named_parameters():
+                if p.grad is not None:
+                    grads[f"{which}.{k}"] = p.grad.cpu().numpy()
+    for i, m in enumerate(maps):
+        grads[f"latent.{i}"] = m.grad.cpu().numpy()
+    return fx, out, float(loss.item()), grads
+
+
+@pytest.mark.parametrize("name", gu.GRAD_CASES)
+def test_gradients_match_reference(name):
+    gfx = gu.load_grad_fixture(name)
+    fx, out, loss, grads = hip_grads(name)
+    # the taped forward is the fp32 path: same tolerance as the inference-precision parity tests
+    assert np.abs(out.coarse.rgb.detach().cpu().numpy() - fx["coarse_rgb"]).max() <= 1e-4
+    assert abs(loss - float(gfx["loss"])) <= 1e-3 * max(1.0, abs(float(gfx["loss"])))
+    compare_grads(grads, gfx, RTOL, name)
+
+
+def test_composite_backward_vs_autograd():
+    from oracle import pixelnerf_oracle as orc
+    from pixel_nerf_multiscale_amd.render.autograd import Composite
+    g = torch.Generator().manual_seed(5)
+    for K, white in ((8, True), (64, False), (96, True), (160, False), (200, True)):
+        B = 37
+        z, _ = torch.sort(torch.rand(B, K, generator=g) * 1.5 + 1.25, dim=-1)
+        rays = torch.cat([torch.randn(B, 6, generator=g), torch.full((B, 1), 1.25), torch.full((B, 1), 2.75)], -1)
+        out = torch.cat([torch.rand(B, K, 3, generator=g), torch.relu(torch.randn(B, K, 1, generator=g) * 8 + 2)], -1)
+        cot = [torch.randn(B, K, generator=g), torch.randn(B, 3, generator=g), torch.randn(B, generator=g)]
+        zo, oo = z.clone().requires_grad_(True), out.clone().requires_grad_(True)
+        w, rgb, d = orc.composite(rays, zo, oo, white)
+        ((w * cot[0]).sum() + (rgb * cot[1]).sum() + (d * cot[2]).sum()).backward()
+        zh, oh = z.cuda().requires_grad_(True), out.cuda().requires_grad_(True)
+        w2, rgb2, d2 = Composite.apply(rays.cuda(), zh, oh, white)
+        ((w2 * cot[0].cuda()).sum() + (rgb2 * cot[1].cuda()).sum() + (d2 * cot[2].cuda()).sum()).backward()
+        for a, b, what in ((oh.grad, oo.grad, "d_out"), (zh.grad, zo.grad, "d_z")):
+            scale = float(b.abs().max())
+            assert float((a.cpu() - b).abs().max()) <= 2e-4 * scale + 1e-6, (K, white, what)
+        # cotangents may be absent (unused outputs)
+        zh2, oh2 = z.cuda().requires_grad_(True), out.cuda().requires_grad_(True)
+        _, rgb3, _ = Composite.apply(rays.cuda(), zh2, oh2, white)
+        (rgb3 * cot[1].cuda()).sum().backward()
+        zo2, oo2 = z.clone().requires_grad_(True), out.clone().requires_grad_(True)
+        _, rgb4, _ = orc.composite(rays, zo2, oo2, white)
+        (rgb4 * cot[1]).sum().backward()
+        assert float((oh2.grad.cpu() - oo2.grad).abs().max()) <= 2e-4 * float(oo2.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("name", ["tiny_ns2_codeview", "tiny_multiscale_ns2", "tiny_max_combine", "full_ns3"])
+def test_point_forward_backward_explicit_points(name):
+    """PixelNeRFNet.forward(xyz, viewdirs) in training mode: outputs and d(xyz), d(weights), d(latents) vs the
+    oracle's point_forward under autograd."""
+    from oracle import pixelnerf_oracle as orc
+    from oracle_util import oracle_setup
+    fx, spec, net, rend = hu.setup(name)
+    net.train()
+    spec, cam, lat, sd_c, sd_f = oracle_setup(fx)
+    xyz = torch.from_numpy(fx["pts_xyz_coarse"]).clone()
+    dirs = torch.from_numpy(fx["pts_dirs_coarse"]).clone()
+    cot = torch.from_numpy(np.random.default_rng(3).standard_normal(fx["pts_out_coarse"].shape).astype(np.float32))
+    # oracle
+    xo = xyz.clone().requires_grad_(True)
+    lo = [m.clone().requires_grad_(True) for m in lat]
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    oo = orc.point_forward(sdo, cam, lo, xo, dirs, spec["NS"], use_code_viewdirs=spec["use_code_viewdirs"],
+                           n_blocks=spec["n_blocks"], combine_layer=spec["combine_layer"], combine_type=spec["combine_type"])
+    (oo * cot).sum().backward()
+    # HIP
+    maps = [m.clone().cuda().requires_grad_(True) for m in lat]
+    net.encoder.set_latents(maps)
+    xh = xyz.cuda().requires_grad_(True)
+    oh = net(xh, coarse=True, viewdirs=dirs.cuda())
+    assert float((oh.detach().cpu() - oo.detach()).abs().max()) <= 1e-4 * max(1.0, float(oo.detach().abs().max()))
+    (oh * cot.cuda()).sum().backward()
+
+    def close(a, b, what):
+        scale = max(float(b.abs().max()), float(b.norm()) / b.numel() ** 0.5)
+        assert float((a.cpu() - b).abs().max()) <= RTOL * scale + 1e-7, (what, float((a.cpu() - b).abs().max()), scale)
+
+    close(xh.grad, xo.grad, "d_xyz")
+    for i, (a, b) in enumerate(zip(maps, lo)):
+        close(a.grad, b.grad, f"d_latent{i}")
+    for k, p in net.mlp_coarse.named_parameters():
+        close(p.grad, sdo[k].grad, k)
+
+
+def test_frozen_encoder_and_eval_mode_routing():
+    """stop_encoder_grad detaches the latents (backup2:228-229); eval() / no_grad() keep the fused kernels."""
+    fx, spec, net, rend = hu.setup("tiny_ns1")
+    rays = torch.from_numpy(fx["rays"]).cuda()
+    assert not net.wants_grad(rays)                       # eval mode
+    net.train()
+    assert net.wants_grad(rays)
+    with torch.no_grad():
+        assert not net.wants_grad(rays)
+    net.stop_encoder_grad = True
+    maps = [torch.from_numpy(x).cuda().requires_grad_(True) for x in gu.make_latents(spec)]
+    net.encoder.set_latents(maps)
+    out = rend(net, rays)
+    out.fine.rgb.sum().backward()
+    assert maps[0].grad is None
+    assert net.mlp_fine.lin_out.weight.grad is not None and net.mlp_coarse.lin_out.weight.grad is not None
+
+
+def test_backward_is_linear_at_training_batch_size():
+    """Size-independent property at a realistic step (SB=2 x 128 rays x (64+32) samples, d_hidden 512, 2 views):
+    grads(G1 + 2 G2) = grads(G1) + 2 grads(G2)."""
+    spec = gu._case(seed=77, d_hidden=512, lat=[(256, 16, 16)], image=(128, 128), focal=131.25, NS=2, SB=2, N=128,
+                    Kc=64, Kf=32, Kfd=16)
+    rays_np, poses_np = gu.make_inputs(spec)
+    net = hu.build_net(spec, poses_np).train()
+    rend = hu.build_renderer(spec)
+    rend.forced_seed = 1234
+    rays = torch.from_numpy(rays_np).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    G1 = torch.randn(2, 128, 3, device="cuda", generator=g)
+    G2 = torch.randn(2, 128, 3, device="cuda", generator=g)
+
+    def run(G):
+        net.zero_grad()
+        out = rend(net, rays)
+        (out.fine.rgb * G).sum().add((out.coarse.rgb * G).sum()).backward()
+        return [p.grad.clone() for p in net.mlp_coarse.parameters()] + [p.grad.clone() for p in net.mlp_fine.parameters()]
+
+    a, b, c = run(G1), run(G2), run(G1 + 2 * G2)
+    for x, y, z in zip(a, b, c):
+        ref = x + 2 * y
+        assert float((z - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6

@@ -104,7 +104,8 @@ class NoiseRecorder:
         torch.rand_like, torch.rand, torch.randn_like = self._orig
 
 
-def run_case(name, spec, NeRFRenderer, PixelNeRFNet):
+def build_case(spec, NeRFRenderer, PixelNeRFNet):
+    """The reference's net + renderer for a spec, with seeded weights and injected latents."""
     torch.manual_seed(spec["seed"])
     net = PixelNeRFNet(model_conf(spec))
     net.eval()
@@ -156,6 +157,11 @@ def run_case(name, spec, NeRFRenderer, PixelNeRFNet):
         n_coarse=spec["Kc"], n_fine=spec["Kf"], n_fine_depth=spec["Kfd"],
         depth_std=spec["depth_std"], white_bkgd=spec["white_bkgd"], lindisp=spec["lindisp"])
     renderer.eval()
+    return net, renderer, enc, rays_np, poses_np
+
+
+def run_case(name, spec, NeRFRenderer, PixelNeRFNet):
+    net, renderer, enc, rays_np, poses_np = build_case(spec, NeRFRenderer, PixelNeRFNet)
 
     # --- record stage intermediates
     rec = {"model_calls": [], "index_calls": [], "mlp_calls": []}

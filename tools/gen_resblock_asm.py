@@ -16,7 +16,7 @@ Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
   * exit: all LDS reads drained, accumulators readable, 65 stages consumed, cursor advanced.
 Register use inside (all declared as clobbers): v10-13 slot read bases, v14 bias address, v15 DMA lane offset,
 v16-19 bias B fragment, v40-55 chunk accumulator (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
-v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 tiles x 2 k-steps x 4), s20-s39.
+v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 tiles x 2 k-steps x 4), s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
 """
 import os
 import sys
@@ -66,7 +66,7 @@ def gen(dt):
             return
         q = f >> 2
         if q == 0:
-            e(f"s_mov_b32 m0, s{30 + k}")
+            e(f"s_mov_b32 m0, s{40 + k}")
             e("s_nop 0")
         e(f"global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
         if q == 3:
@@ -106,7 +106,7 @@ def gen(dt):
         e(f"s_add_u32 s35, s22, {1 + k}")
         e("s_and_b32 s35, s35, 3")
         e("s_lshl_b32 s35, s35, 14")
-        e(f"s_add_u32 s{30 + k}, s35, %23")
+        e(f"s_add_u32 s{40 + k}, s35, %23")
     e("v_mov_b32 v14, %26")
     e("v_mov_b32 v15, %25")
     e("v_mov_b32 v16, %27")
@@ -213,7 +213,7 @@ def gen_xstages(dt):
         e("2:")
 
     def stage_body(breg):
-        # cur base v10, nxt base v11, M0 value s30, B fragment in v[breg:breg+3]
+        # cur base v10, nxt base v11, M0 value s40, B fragment in v[breg:breg+3]
         e("s_waitcnt vmcnt(4)")
         e("s_barrier")
         for f in range(16):
@@ -225,7 +225,7 @@ def gen_xstages(dt):
             if f % 4 == 1:
                 q = f >> 2
                 if q == 0:
-                    e("s_mov_b32 m0, s30")
+                    e("s_mov_b32 m0, s40")
                     e("s_nop 0")
                 e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
                 if q == 3:
@@ -242,7 +242,7 @@ def gen_xstages(dt):
         e("s_lshl_b32 s35, s35, 14")
         e("v_add_u32 v11, s35, %24")                          # nxt
         e("s_lshl_b32 s35, s22, 14")
-        e("s_add_u32 s30, s35, %23")                          # DMA destination of the stage being loaded
+        e("s_add_u32 s40, s35, %23")                          # DMA destination of the stage being loaded
 
     e("s_nop 15")
     e("s_nop 15")
@@ -267,7 +267,7 @@ def gen_xstages(dt):
     e("s_lshl_b32 s35, s35, 14")
     e("v_add_u32 v11, s35, %24")                              # nxt
     e("s_lshl_b32 s35, s22, 14")
-    e("s_add_u32 s30, s35, %23")
+    e("s_add_u32 s40, s35, %23")
     e("v_mov_b32 v14, %26")
     e("v_mov_b32 v15, %25")
     e("ds_read_b128 v[16:19], v14")                           # B of the first k-step
@@ -405,7 +405,7 @@ def main():
                 f.write(f'    "{l}\\n\\t" \\\n')
             f.write('    ""\n\n')
         clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 20)) + list(range(40, 56)) + list(range(60, 72)) + list(range(96, 256))] \
-            + [f"s{i}" for i in range(20, 40)]
+            + [f"s{i}" for i in list(range(20, 32)) + list(range(33, 44))]
         f.write("#define PNR_RESBLOCK_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
     # audit: every physical v/s register the text names must be declared clobbered (operands are %N references)
     import re
