@@ -9,7 +9,7 @@ namespace pnr {
 // col = v*CH + pl for point g0+pl of the chunk and source view v (view index obj*NS+v).
 static __global__ void k_features_f32(pnr_views vw, PointSrc src, int64_t g0, int CH, int64_t pts_per_obj,
                                int L, int d_in, int use_code_viewdirs, int num_freqs, float freq_factor,
-                               float* __restrict__ zx) {
+                               float* __restrict__ zx, int ldz /* row stride of zx, >= L + d_in */) {
     const int E = L + d_in;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)CH * vw.n_views * E;
@@ -49,7 +49,7 @@ static __global__ void k_features_f32(pnr_views vw, PointSrc src, int64_t g0, in
             val = (j < dcode) ? posenc_elem(xr, 3, j, freq_factor) : dr[j - dcode];
         }
     }
-    zx[idx] = val;
+    zx[(size_t)col * ldz + e] = val;
 }
 
 // Y[M,N] (+)= act(X[M,K]) W[N,K]^T + b ;  64x64 tile, K-step 16, 4x4 per thread, k-ordered fmaf chain.

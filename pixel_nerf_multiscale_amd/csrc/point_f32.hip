@@ -35,7 +35,7 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         int CH = (int)((n_points - g0 < F32_CHUNK) ? (n_points - g0) : F32_CHUNK);
         int64_t tot = (int64_t)CH * NS * E;
         hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, g0, CH,
-                           pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx);
+                           pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E);
         PNR_LAUNCH_CHECK();
         int M = CH * NS;
         int32_t rc;

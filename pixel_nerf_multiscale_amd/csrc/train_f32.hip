@@ -137,6 +137,165 @@ static __global__ void __launch_bounds__(256) k_grad_w_f32(
     }
 }
 
+// ------------------------------------------------------------------ fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32)
+// C[M,N] = R + mask( sum_r act(A(m,r)) B(r,n) + bias[n] )   or   C += ... (atomics, SPLIT over r)
+//   A_RC: A stored (M, R) r-contiguous (lda) — else stored (R, M) m-contiguous
+//   B_RC: B stored (N, R) r-contiguous (ldb) — else stored (R, N) n-contiguous
+// forward  y = x W^T   : A_RC, B_RC          dX = dY W : A_RC, !B_RC          dW = dY^T x : !A_RC, !B_RC (SPLIT)
+// 128x128 tile per 256-thread block, 4 waves x (2x2) 32x32 accumulators, r-step 16 through LDS (A and B
+// tiles stored r-major so a fragment read is 64 consecutive floats), register-staged global prefetch of
+// the next r-tile behind the MFMAs.  One float per lane per operand: a = A[row = l%32][r = l/32],
+// b = B[r = l/32][col = l%32]; acc[j] = C[8*(j/4) + 4*(l/32) + j%4][l%32].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Loads are unconditional (indices clamped into the operand, the value zeroed afterwards): a predicated
+// load would put a branch and a full vmcnt(0) wait in front of every element.
+template <bool RC>
+__device__ __forceinline__ void mg_fetch(const float* __restrict__ S, int ld, int x0, int X, int r0, int r1, bool relu,
+                                         float (&v)[8]) {
+    const int t = threadIdx.x;
+    if (RC) {           // stored (X, R): thread -> (row = t/4 + 64 i, 4 r's at 4*(t%4))
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int x = x0 + (t >> 2) + 64 * i, r = r0 + 4 * (t & 3);
+            const float* p = S + (size_t)min(x, X - 1) * ld;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float val = p[min(r + e, r1 - 1)];
+                val = (x < X && r + e < r1) ? val : 0.f;
+                v[i * 4 + e] = relu ? fmaxf(val, 0.f) : val;
+            }
+        }
+    } else {            // stored (R, X): thread -> (r = t/32 + 8 i, 4 x's at 4*(t%32))
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + (t >> 5) + 8 * i, x = x0 + 4 * (t & 31);
+            const float* p = S + (size_t)min(r, r1 - 1) * ld;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float val = p[min(x + e, X - 1)];
+                val = (r < r1 && x + e < X) ? val : 0.f;
+                v[i * 4 + e] = relu ? fmaxf(val, 0.f) : val;
+            }
+        }
+    }
+}
+
+// Interior tiles of 16-byte-aligned operands: plain float4 loads, no bounds logic.
+template <bool RC>
+__device__ __forceinline__ void mg_fetch_fast(const float* __restrict__ S, int ld, int x0, int r0, bool relu, float (&v)[8]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4* p = RC ? (const float4*)(S + (size_t)(x0 + (t >> 2) + 64 * i) * ld + r0 + 4 * (t & 3))
+                             : (const float4*)(S + (size_t)(r0 + (t >> 5) + 8 * i) * ld + x0 + 4 * (t & 31));
+        float4 q = *p;
+        v[i * 4 + 0] = relu ? fmaxf(q.x, 0.f) : q.x;
+        v[i * 4 + 1] = relu ? fmaxf(q.y, 0.f) : q.y;
+        v[i * 4 + 2] = relu ? fmaxf(q.z, 0.f) : q.z;
+        v[i * 4 + 3] = relu ? fmaxf(q.w, 0.f) : q.w;
+    }
+}
+
+template <bool RC>
+__device__ __forceinline__ void mg_stage(float (*T)[132], const float (&v)[8]) {
+    const int t = threadIdx.x;
+    if (RC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[4 * (t & 3) + e][(t >> 2) + 64 * i] = v[i * 4 + e];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(t >> 5) + 8 * i][4 * (t & 31) + e] = v[i * 4 + e];
+    }
+}
+
+template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
+static __global__ void __launch_bounds__(256) k_mgemm_f32(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
+    int M, int N, int Rn, int r_per_split, int vec_ok) {
+    __shared__ float As[2][16][132];
+    __shared__ float Bs[2][16][132];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float va[8], vb[8];
+    float rs = 0.f;
+    const bool fast_a = (vec_ok & 1) && m0 + 128 <= M, fast_b = (vec_ok & 2) && n0 + 128 <= N;   // block-uniform
+    auto fetch = [&](int r) {
+        const bool full = r + 16 <= re;
+        if (fast_a && full) mg_fetch_fast<A_RC>(A, lda, m0, r, RELU_A, va);
+        else mg_fetch<A_RC>(A, lda, m0, M, r, re, RELU_A, va);
+        if (fast_b && full) mg_fetch_fast<B_RC>(B, ldb, n0, r, RELU_B, vb);
+        else mg_fetch<B_RC>(B, ldb, n0, N, r, re, RELU_B, vb);
+    };
+    fetch(rb);
+    mg_stage<A_RC>(As[0], va);
+    mg_stage<B_RC>(Bs[0], vb);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = rb; r0 < re; r0 += 16) {
+        const bool more = r0 + 16 < re;
+        if (more) fetch(r0 + 16);
+        const int lr = lane >> 5, lc = lane & 31;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a0 = As[buf][2 * s + lr][wm + lc], a1 = As[buf][2 * s + lr][wm + 32 + lc];
+            float b0 = Bs[buf][2 * s + lr][wn + lc], b1 = Bs[buf][2 * s + lr][wn + 32 + lc];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (rowsum && blockIdx.y == 0 && t < 128) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs += As[buf][r][t];
+        }
+        if (more) {
+            mg_stage<A_RC>(As[buf ^ 1], va);
+            mg_stage<B_RC>(Bs[buf ^ 1], vb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int lr = lane >> 5, lc = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lc;
+            if (n >= N) continue;
+            const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bn;
+                if (SPLIT) {
+                    atomicAdd(C + (size_t)m * ldc + n, v);
+                } else {
+                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
+                    if (R) v += R[(size_t)m * ldr + n];
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+        }
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+}
+
 // d(pre-activation) of the output head: rgb = sigmoid(o) -> y(1-y); sigma = relu(o) -> [y > 0]
 static __global__ void k_out_act_bwd(const float4* __restrict__ out, const float4* __restrict__ d_out, int64_t n,
                                      float4* __restrict__ d_o4) {
@@ -179,12 +338,11 @@ struct LatGrad { float* p[PNR_MAX_LEVELS]; };
 
 static __global__ void __launch_bounds__(256) k_features_bwd(
     pnr_views vw, PointSrc src, int64_t P, int64_t pts_per_obj, int L, int d_in, int use_code_viewdirs,
-    int num_freqs, float freq_factor, const float* __restrict__ dzx, LatGrad dl, float* __restrict__ d_xyz,
+    int num_freqs, float freq_factor, const float* __restrict__ dzx, int ldz, LatGrad dl, float* __restrict__ d_xyz,
     float* __restrict__ d_z) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= P) return;
-    const int E = L + d_in;
     const bool want_p = (d_xyz != nullptr) || (d_z != nullptr);
     float p[3], d[3];
     fetch_point(src, g, p, d);
@@ -197,7 +355,7 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
         rot3(cam.R, p, xr);
         float u, w;
         project(cam, xr, u, w);
-        const float* drow = dzx + ((size_t)v * P + g) * E;
+        const float* drow = dzx + ((size_t)v * P + g) * ldz;
         float du = 0.f, dv = 0.f;
         int c0 = 0;
         for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
@@ -390,7 +548,7 @@ static inline uint64_t a256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
 static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void* base) {
     Tape t{};
-    const int NS = vw->n_views, H = mlp->d_hidden, E = mlp->d_latent + mlp->d_in;
+    const int NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;   // padded row stride
     uint8_t* p = (uint8_t*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
     uint64_t off = 0;
     auto take = [&](uint64_t floats) { float* r = (float*)(p + off); off += a256(floats * 4); return r; };
@@ -411,14 +569,25 @@ uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
 }
 
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
-    const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = mlp->d_latent + mlp->d_in;
+    const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;
     return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + 256;
+}
+
+static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
+    return ((((uintptr_t)A & 15) == 0 && lda % 4 == 0) ? 1 : 0) | ((((uintptr_t)B & 15) == 0 && ldb % 4 == 0) ? 2 : 0);
 }
 
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
                     const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
     if (M == 0) return PNR_OK;
+    if (N >= 32 && K >= 16) {       // MFMA tile kernel; the skinny heads (N = 4, K = 4) stay on the FMA kernel
+        dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+        hipLaunchKernelGGL((k_mgemm_f32<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
+                           Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0, vec_flags(X, ldx, W, ldw));
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
     hipLaunchKernelGGL((k_gemm_f32<RELU_X, TRANS_W>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr, Mk, ldm, Y,
                        ldy, (int)M, N, K);
@@ -426,10 +595,21 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
     return PNR_OK;
 }
 
+// dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
                       int N, int K, hipStream_t s) {
     if (!dW || M == 0) return PNR_OK;
+    if (N >= 32 && K >= 32) {
+        // dW = A B with A(n, r = m) = dY[m][n] and B(r = m, k) = act(X[m][k]): both stored reduction-major
+        const int rows = 1024;
+        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));
+        hipLaunchKernelGGL((k_mgemm_f32<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                           (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
+                           N, K, (int)M, rows, vec_flags(dY, ldy, X, ldx));
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     const int rows = 2048;
     dim3 grid((N + 63) / 64, (K + 63) / 64, (unsigned)((M + rows - 1) / rows));
     hipLaunchKernelGGL((k_grad_w_f32<RELU_X>), grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, (int)M, N, K, rows);
@@ -442,17 +622,17 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
 int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
                         int64_t pts_per_obj, float* out, void* tape, uint64_t tape_bytes, hipStream_t s) {
     if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
-    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden, E = L + Din;
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
+    const int E = (L + Din + 3) & ~3;      // row stride of zx (16-byte rows for the vector loads)
     const int nb = mlp->n_blocks, cl = mlp->combine_layer;
     if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
-    if ((int64_t)NS * P * E > 0x7fffffffLL * 64) return PNR_E_SHAPE;
     Tape t = carve_tape(mlp, vw, P, tape);
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
-    int64_t tot = MV * E;
+    int64_t tot = MV * (L + Din);
     hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
-                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx);
+                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
@@ -487,7 +667,8 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                   uint64_t ws_bytes, hipStream_t s) {
     if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
     if (ws_bytes < train_bwd_workspace_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
-    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden, E = L + Din;
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
+    const int E = (L + Din + 3) & ~3;
     const int nb = mlp->n_blocks, cl = mlp->combine_layer;
     if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
     Tape t = carve_tape(mlp, vw, P, tape);
@@ -539,7 +720,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s)));
     if (want_p || (want_lat && L > 0)) {
         hipLaunchKernelGGL(k_features_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, *vw, src, P, pts_per_obj, L, Din,
-                           prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, lg, d_xyz, d_z);
+                           prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, E, lg, d_xyz, d_z);
         PNR_LAUNCH_CHECK();
     }
     return PNR_OK;
