@@ -197,9 +197,13 @@ __device__ __forceinline__ void mg_fetch_fast(const float* __restrict__ S, int l
     }
 }
 
-template <bool RC>
-__device__ __forceinline__ void mg_stage(float (*T)[132], const float (&v)[8]) {
+template <bool RC, bool RELU>
+__device__ __forceinline__ void mg_stage(float (*T)[132], float (&v)[8]) {
     const int t = threadIdx.x;
+    if (RELU) {          // applied here, not at the fetch: a use right behind the load would stall on it
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
     if (RC) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -207,9 +211,8 @@ __device__ __forceinline__ void mg_stage(float (*T)[132], const float (&v)[8]) {
             for (int e = 0; e < 4; ++e) T[4 * (t & 3) + e][(t >> 2) + 64 * i] = v[i * 4 + e];
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) T[(t >> 5) + 8 * i][4 * (t & 31) + e] = v[i * 4 + e];
+        for (int i = 0; i < 2; ++i)      // rows are 528 B apart: one 16-byte store per thread, conflict-free
+            *(float4*)&T[(t >> 5) + 8 * i][4 * (t & 31)] = make_float4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
     }
 }
 
@@ -237,36 +240,58 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
     const bool fast_a = (vec_ok & 1) && m0 + 128 <= M, fast_b = (vec_ok & 2) && n0 + 128 <= N;   // block-uniform
     auto fetch = [&](int r) {
         const bool full = r + 16 <= re;
-        if (fast_a && full) mg_fetch_fast<A_RC>(A, lda, m0, r, RELU_A, va);
-        else mg_fetch<A_RC>(A, lda, m0, M, r, re, RELU_A, va);
-        if (fast_b && full) mg_fetch_fast<B_RC>(B, ldb, n0, r, RELU_B, vb);
-        else mg_fetch<B_RC>(B, ldb, n0, N, r, re, RELU_B, vb);
+        if (fast_a && full) mg_fetch_fast<A_RC>(A, lda, m0, r, false, va);
+        else mg_fetch<A_RC>(A, lda, m0, M, r, re, false, va);
+        if (fast_b && full) mg_fetch_fast<B_RC>(B, ldb, n0, r, false, vb);
+        else mg_fetch<B_RC>(B, ldb, n0, N, r, re, false, vb);
     };
+    // Software pipeline: tile i's MFMAs run with tile i+1 already in LDS (staged before them, from registers
+    // fetched one iteration earlier) and tile i+2 in flight from global memory.
     fetch(rb);
-    mg_stage<A_RC>(As[0], va);
-    mg_stage<B_RC>(Bs[0], vb);
+    mg_stage<A_RC, RELU_A>(As[0], va);
+    mg_stage<B_RC, RELU_B>(Bs[0], vb);
+    if (rb + 16 < re) fetch(rb + 16);
     __syncthreads();
     int buf = 0;
     for (int r0 = rb; r0 < re; r0 += 16) {
-        const bool more = r0 + 16 < re;
-        if (more) fetch(r0 + 16);
+        if (r0 + 16 < re) {
+            mg_stage<A_RC, RELU_A>(As[buf ^ 1], va);
+            mg_stage<B_RC, RELU_B>(Bs[buf ^ 1], vb);
+            if (r0 + 32 < re) fetch(r0 + 32);
+        }
         const int lr = lane >> 5, lc = lane & 31;
+        // 4 groups of 2 r-steps; group g+1's fragments are read while group g's 8 MFMAs (512 cycles) run
+        float fa[2][4], fb[2][4];
+        auto frag = [&](int g, float (&a)[4], float (&b)[4]) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            float a0 = As[buf][2 * s + lr][wm + lc], a1 = As[buf][2 * s + lr][wm + 32 + lc];
-            float b0 = Bs[buf][2 * s + lr][wn + lc], b1 = Bs[buf][2 * s + lr][wn + 32 + lc];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * (2 * g + q) + lr;
+                a[2 * q] = As[buf][r][wm + lc]; a[2 * q + 1] = As[buf][r][wm + 32 + lc];
+                b[2 * q] = Bs[buf][r][wn + lc]; b[2 * q + 1] = Bs[buf][r][wn + 32 + lc];
+            }
+        };
+        frag(0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) frag(g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+            float(&a)[4] = fa[g & 1];
+            float(&b)[4] = fb[g & 1];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q], b[2 * q], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q], b[2 * q + 1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q + 1], b[2 * q], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q + 1], b[2 * q + 1], acc[1][1], 0, 0, 0);
+            }
+            if (g < 3) {        // keep the next group's reads ahead of this group's MFMAs in the schedule
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
         if (rowsum && blockIdx.y == 0 && t < 128) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) rs += As[buf][r][t];
-        }
-        if (more) {
-            mg_stage<A_RC>(As[buf ^ 1], va);
-            mg_stage<B_RC>(Bs[buf ^ 1], vb);
         }
         __syncthreads();
         buf ^= 1;
@@ -294,6 +319,29 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
             }
         }
     if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+}
+
+// dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4): one thread per k
+// column walks a slice of the rows (X read once, coalesced; dY rows broadcast).  HBM-bound: 4 K bytes per row.
+template <bool RELU_X>
+static __global__ void __launch_bounds__(256) k_grad_w_head(const float4* __restrict__ dY, const float* __restrict__ X,
+                                                            int ldx, float* __restrict__ dW, int ldw,
+                                                            float* __restrict__ db, int M, int K, int rows_per_split) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int mb = blockIdx.y * rows_per_split, me = min(M, mb + rows_per_split);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    const bool live = k < K;
+    for (int m = mb; m < me; ++m) {
+        float4 g = dY[m];
+        float x = live ? X[(size_t)m * ldx + k] : 0.f;
+        if (RELU_X) x = fmaxf(x, 0.f);
+        a0 = fmaf(g.x, x, a0); a1 = fmaf(g.y, x, a1); a2 = fmaf(g.z, x, a2); a3 = fmaf(g.w, x, a3);
+        b0 += g.x; b1 += g.y; b2 += g.z; b3 += g.w;
+    }
+    if (live) {
+        atomicAdd(dW + k, a0); atomicAdd(dW + ldw + k, a1); atomicAdd(dW + 2 * ldw + k, a2); atomicAdd(dW + 3 * ldw + k, a3);
+    }
+    if (db && k == 0) { atomicAdd(db, b0); atomicAdd(db + 1, b1); atomicAdd(db + 2, b2); atomicAdd(db + 3, b3); }
 }
 
 // d(pre-activation) of the output head: rgb = sigmoid(o) -> y(1-y); sigma = relu(o) -> [y > 0]
@@ -607,6 +655,13 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
         hipLaunchKernelGGL((k_mgemm_f32<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                            (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
                            N, K, (int)M, rows, vec_flags(dY, ldy, X, ldx));
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
+    if (N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0) {
+        const int rows = 256;
+        dim3 grid((K + 255) / 256, (unsigned)((M + rows - 1) / rows));
+        hipLaunchKernelGGL((k_grad_w_head<RELU_X>), grid, dim3(256), 0, s, (const float4*)dY, X, ldx, dW, ldw, db, (int)M, K, rows);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }

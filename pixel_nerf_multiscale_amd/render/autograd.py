@@ -96,8 +96,12 @@ class PointMLP(torch.autograd.Function):
         v, k2 = views_from(poses, focal, c, hdr["n_views"], maps)
         need = ctx.needs_input_grad            # (hdr, a, b, poses, focal, c, *params, *maps)
         need_par, need_map = need[6:6 + n_par], need[6 + n_par:]
-        g_par = [torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) if nd else None
-                 for p, nd in zip(params, need_par)]
+        # one zero fill for all parameter gradients (the kernels accumulate with atomics)
+        flat = torch.zeros(sum(p.numel() for p, nd in zip(params, need_par) if nd), device=dev)
+        g_par, off = [], 0
+        for p, nd in zip(params, need_par):
+            g_par.append(flat[off:off + p.numel()].view(p.shape) if nd else None)
+            off += p.numel() if nd else 0
         g_map = [torch.zeros(mp.shape, device=dev) if nd else None for mp, nd in zip(maps, need_map)]
         rays_mode = hdr["rays_mode"]
         n_points = out.shape[0]
