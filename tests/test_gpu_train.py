@@ -161,3 +161,48 @@ def test_backward_is_linear_at_training_batch_size():
     for x, y, z in zip(a, b, c):
         ref = x + 2 * y
         assert float((z - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6
+
+
+def test_training_abi_error_codes_and_empty_batch():
+    """Argument errors of the training entry points come back as PNR_E_* codes (no faults, no exceptions)."""
+    import ctypes as C
+    from pixel_nerf_multiscale_amd import _native as N
+    fx, spec, net, rend = hu.setup("tiny_ns1")
+    rays = torch.from_numpy(fx["rays"]).cuda().reshape(-1, 8)
+    n, K = rays.shape[0], 8
+    z = torch.rand(n, K, device="cuda").sort(dim=-1)[0] + 1.5
+    prm = net.params_struct(None, "fp32")
+    m, k1 = net.mlp_struct(net.mlp_coarse, "fp32")
+    v, k2 = net.views_struct("fp32")
+    s = N.current_stream(rays.device)
+    P = n * K
+    tb = N.lib.pnr_train_tape_bytes(C.byref(m), C.byref(v), P)
+    wb = N.lib.pnr_train_bwd_workspace_bytes(C.byref(m), C.byref(v), P)
+    assert tb > 0 and wb > 0
+    tape = torch.empty(tb, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    out = torch.empty(P, 4, device="cuda")
+    d_out = torch.randn(P, 4, device="cuda")
+    g = N.pnr_mlp_grads()
+    fwd = lambda tbytes=tb, npts=P, o=out: N.lib.pnr_point_mlp_train_fwd(
+        C.byref(prm), C.byref(m), C.byref(v), N.ptr(rays), N.ptr(z), K, None, None, npts, npts, N.ptr(o) if o is not None else None,
+        tape.data_ptr(), tbytes, s)
+    assert fwd() == 0
+    assert fwd(tbytes=tb // 2) == -4                       # tape too small
+    assert fwd(npts=P - 1) == -2                           # not a multiple of K
+    assert fwd(o=None) == -1
+    bwd = lambda wbytes=wb, dxyz=None, grads=g: N.lib.pnr_point_mlp_bwd(
+        C.byref(prm), C.byref(m), C.byref(v), N.ptr(rays), N.ptr(z), K, None, None, P, P, N.ptr(out), N.ptr(d_out),
+        tape.data_ptr(), tb, C.byref(grads) if grads is not None else None, None, dxyz, None, ws.data_ptr(), wbytes, s)
+    assert bwd() == 0                                      # all gradient pointers NULL: nothing to write, still fine
+    assert bwd(wbytes=wb // 2) == -4
+    assert bwd(dxyz=out.data_ptr()) == -2                  # d_xyz belongs to explicit points, d_z to rays
+    assert bwd(grads=None) == -1
+    v2 = N.pnr_views.from_buffer_copy(v); v2.latent[0] = None
+    assert N.lib.pnr_point_mlp_train_fwd(C.byref(prm), C.byref(m), C.byref(v2), N.ptr(rays), N.ptr(z), K, None, None, P, P,
+                                         N.ptr(out), tape.data_ptr(), tb, s) == -1        # needs the fp32 maps
+    assert N.lib.pnr_composite_bwd(N.ptr(rays), N.ptr(z), out.data_ptr() + 4, n, K, 1, None, None, None, N.ptr(d_out), None, s) == -5
+    assert N.lib.pnr_sample_fine_bwd(N.ptr(rays), None, n, 8, 4, 2, 0.01, None, 1, 0, N.ptr(z), N.ptr(z), N.ptr(z), s) == -1
+    assert N.lib.pnr_point_mlp_train_fwd(C.byref(prm), C.byref(m), C.byref(v), N.ptr(rays), N.ptr(z), K, None, None, 0, 1,
+                                         N.ptr(out), None, 0, s) in (0, -2)               # empty batch: no launch
+    torch.cuda.synchronize()
