@@ -61,7 +61,8 @@ typedef struct pnr_mlp {
     const void* packed;
     uint64_t packed_bytes;
     int32_t packed_dtype;        /* PNR_BF16 / PNR_F16 */
-    int32_t reserved1;
+    int32_t packed_texels;       /* 0: plain stream (pnr_pack_mlp).  T > 0: stream from pnr_pack_mlp_projected for a
+                                  * single latent map of T = Hl*Wl texels (lin_z pre-multiplied with the map) */
 } pnr_mlp;
 
 /* What PixelNeRFNet.encode() leaves on the module (models.py.backup2:108-150) + the encoder's latent
@@ -137,6 +138,15 @@ const char* pnr_error_string(int32_t code);
  * (bf16 or fp16; biases folded in).  `out` must hold pnr_packed_mlp_bytes() bytes, 16-B aligned. */
 uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
 int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
+/* Projected stream: for ONE source view with ONE small latent map (views->n_objs * n_views == 1, n_levels == 1,
+ * 4 <= Hl*Wl <= 128 — the SRN / NMR single-view evaluation shape) bilinear lookup and lin_z are both linear, so
+ * lin_z_b(index(uv)) = (W_z,b . Lat) . w(uv) with w the point's 4 tap weights spread over the Hl*Wl texels.  The
+ * stream then carries W_z,b . Lat (512 x Hl*Wl) in place of W_z,b (512 x d_latent) and the kernel needs no latent
+ * gather.  Re-pack whenever the weights OR the latent map change; pnr_packed_mlp_projected_bytes() returns 0 when
+ * the shapes do not qualify.  Set pnr_mlp.packed_texels = Hl*Wl on the struct that carries this stream. */
+uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views);
+int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,
+                               uint64_t out_bytes, void* stream);
 /* Channels-last low-precision copy of the latent maps for the MFMA kernel's gather. */
 uint64_t pnr_packed_latent_bytes(const pnr_views* views);
 /* level_offsets (host array of PNR_MAX_LEVELS, may be NULL) receives the byte offset of every level inside `out` */

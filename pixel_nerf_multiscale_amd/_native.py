@@ -29,7 +29,7 @@ class pnr_mlp(C.Structure):
         ("fc0_w", _fp * PNR_MAX_BLOCKS), ("fc0_b", _fp * PNR_MAX_BLOCKS),
         ("fc1_w", _fp * PNR_MAX_BLOCKS), ("fc1_b", _fp * PNR_MAX_BLOCKS),
         ("lin_out_w", _fp), ("lin_out_b", _fp),
-        ("packed", _fp), ("packed_bytes", C.c_uint64), ("packed_dtype", C.c_int32), ("reserved1", C.c_int32),
+        ("packed", _fp), ("packed_bytes", C.c_uint64), ("packed_dtype", C.c_int32), ("packed_texels", C.c_int32),
     ]
 
 
@@ -79,6 +79,8 @@ PROTOTYPES = {
     "pnr_error_string": (C.c_char_p, [_i32]),
     "pnr_packed_mlp_bytes": (_u64, [C.POINTER(pnr_mlp)]),
     "pnr_pack_mlp": (_i32, [C.POINTER(pnr_mlp), _i32, _fp, _u64, _fp]),
+    "pnr_packed_mlp_projected_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views)]),
+    "pnr_pack_mlp_projected": (_i32, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i32, _fp, _u64, _fp]),
     "pnr_packed_latent_bytes": (_u64, [C.POINTER(pnr_views)]),
     "pnr_pack_latents": (_i32, [C.POINTER(pnr_views), _i32, _fp, _u64, C.POINTER(C.c_uint64), _fp]),
     "pnr_sample_coarse": (_i32, [_fp, _i64, _i32, _i32, _fp, _u64, _i64, _fp, _fp]),

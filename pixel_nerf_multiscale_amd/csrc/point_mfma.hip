@@ -106,13 +106,17 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t p) {
 // Stage = 16 fragments of 1 KiB.  Per (tile, view):  LIN_IN (S_in stages), then per phase-1 block
 // [LIN_Z: SZ stages + 1 bias stage] [fc_1 bias stage] [16 chunks x (2 fc_0 + 2 fc_1 stages)];
 // phase 2: per block [fc_1 bias stage][16 x 4]; LIN_OUT 2 stages.
+// Projected mode (proj_T > 0; one source view, one small latent map of T texels): bilinear interpolation and lin_z are
+// both linear, so lin_z_b(z(p)) = (W_z,b . Lat) . w(p) with w(p) the T-vector of the point's 4 tap weights.  The
+// stream then carries the (512 x T) products M_b = W_z,b . Lat in place of W_z,b: ceil(T/16) k-steps instead of L/16,
+// and the per-point latent gather disappears (the B operand is the tap-weight image).
 struct Layout {
-    int d_in, d_in_pad, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats;
-    uint64_t btab_bytes, stream_bytes, total_bytes;
+    int d_in, d_in_pad, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK;
+    uint64_t btab_bytes, stream_bytes, total_bytes, proj_bytes;
 };
 static constexpr int BLOCK_STAGES = 1 + 16 * 4;
 
-__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y) {
+__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0) {
     if (m.d_hidden != HID || m.d_out != 4 || m.d_latent <= 0 || (m.d_latent % 256) != 0 || m.d_latent > 1024) return false;
     if (m.n_blocks < 1 || m.n_blocks > PNR_MAX_BLOCKS || m.d_in < 1 || m.d_in > 78) return false;
     y.d_in = m.d_in;
@@ -120,7 +124,10 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y) {
     y.S_in = y.d_in_pad / 16;
     if (y.S_in > 5) return false;
     y.L = m.d_latent;
-    y.SZ = m.d_latent / 16;
+    if (proj_T < 0 || proj_T > 128) return false;
+    y.proj_T = proj_T;
+    y.SZ = proj_T > 0 ? (proj_T + 15) / 16 : m.d_latent / 16;
+    y.ZK = y.SZ * 16;                               // k extent of a lin_z stage group
     y.n_blocks = m.n_blocks;
     y.nb1 = m.combine_layer < m.n_blocks ? m.combine_layer : m.n_blocks;
     if (y.nb1 < 0) y.nb1 = 0;
@@ -130,7 +137,8 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y) {
     y.btab_floats = ((m.n_blocks * HID + 4 + 63) / 64) * 64;
     y.btab_bytes = (uint64_t)y.btab_floats * 4;
     y.stream_bytes = (uint64_t)(y.P1 + y.P2) * STAGE_BYTES;
-    y.total_bytes = y.btab_bytes + y.stream_bytes;
+    y.proj_bytes = proj_T > 0 ? (uint64_t)(y.nb1 > 0 ? y.nb1 : 1) * HID * y.ZK * 4 : 0;   // fp32 M_b scratch behind the stream
+    y.total_bytes = y.btab_bytes + y.stream_bytes + y.proj_bytes;
     return true;
 }
 
@@ -139,8 +147,24 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y) {
 __host__ __device__ inline int perm_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // ---------------------------------------------------------------------------- pack kernels
+// M_b[n][t] = sum_c lin_z[b].weight[n][c] * latent[c][t]  (fp32; view 0 of a single-level latent), t padded to ZK with 0
+__global__ void k_project_latent(pnr_mlp m, Layout y, const float* __restrict__ lat, int T, float* __restrict__ M) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n_out = (int64_t)y.nb1 * HID * y.ZK;
+    if (i >= n_out) return;
+    int t = (int)(i % y.ZK);
+    int n = (int)((i / y.ZK) % HID);
+    int b = (int)(i / ((int64_t)y.ZK * HID));
+    float acc = 0.f;
+    if (t < T) {
+        const float* w = m.lin_z_w[b] + (size_t)n * y.L;
+        for (int c = 0; c < y.L; ++c) acc = fmaf(w[c], lat[(size_t)c * T + t], acc);
+    }
+    M[i] = acc;
+}
+
 template <int DT>
-__global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out) {
+__global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const float* __restrict__ M) {
     // bias table
     float* bt = (float*)out;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < y.btab_floats; i += gridDim.x * blockDim.x) {
@@ -184,7 +208,7 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out) {
             if (in_blk >= 0) {
                 if (in_blk < y.SZ) {                    // LIN_Z k-step in_blk: natural k
                     int n = 32 * f + r, k = 16 * in_blk + 8 * h + j;
-                    val = m.lin_z_w[b][(size_t)n * y.L + k];
+                    val = M ? M[((size_t)b * HID + n) * y.ZK + k] : m.lin_z_w[b][(size_t)n * y.L + k];
                 } else if (in_blk == y.SZ || in_blk == y.SZ + 1) {   // bias stages: k-slot 0 = hi, 1 = lo
                     const float* bp = (in_blk == y.SZ) ? m.lin_z_b[b] : m.fc1_b[b];
                     int n = 32 * f + r;
@@ -244,7 +268,7 @@ struct MfmaArgs {
     float* out;
     float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
     int n_tiles, NS, combine_max;
-    int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in;
+    int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj;
     int use_code_viewdirs, num_freqs;
     float freq_factor;
 };
@@ -486,7 +510,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         return hacc;
     };
 
-    const int n_groups = a.SZ / 16;               // latent channel groups of 256 (the LDS image holds one)
+    const int n_groups = a.proj ? 1 : a.SZ / 16;  // latent channel groups of 256 (the LDS image holds one)
+    const int z_steps = a.proj ? a.SZ : 16;       // k-steps per lin_z call (projected: the texel k-steps)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         STAMP(st_t);
 #ifdef PNR_STAMPS
@@ -548,6 +573,21 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             }
         };
 
+        // ---- projected mode: the B operand of lin_z is the point's tap-weight vector over the T texels,
+        //      image [k-step][lane half][col][8]: texel t sits at k-step t/16, half (t/8)&1, element t&7
+        auto tap_image = [&]() {
+            const Taps tp = bilinear_taps(pu, pv, a.vw.lat_w[0], a.vw.lat_h[0]);
+            const uint4 z4 = {0u, 0u, 0u, 0u};
+            for (int s = 0; s < a.SZ; ++s) *(uint4*)(zwave + s * 1024 + lane * 16) = z4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = tp.off[2 * h + i];
+                const float w = tp.w[2 * h + i];
+                if (w != 0.f)
+                    *(uint16_t*)(zwave + (t >> 4) * 1024 + ((((t >> 3) & 1) * 32 + r) * 16) + (t & 7) * 2) = NM::cvt(w);
+            }
+        };
+
         while (true) {
             if (start) {
                 start = false;
@@ -598,7 +638,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #else
                 x_stages(a.S_in, 0);
 #endif
-                if (n_groups == 1) gather(0);
+                if (a.proj) tap_image();
+                else if (n_groups == 1) gather(0);
                 STAMP_ACC(2, st_t);
             }
             // ---- x += lin_z[b](z)  (blocks before the view reduction only)
@@ -606,9 +647,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 for (int grp = 0; grp < n_groups; ++grp) {
                     if (n_groups > 1) gather(grp);
 #ifdef PNR_X_NO_ASM_LINZ
-                    x_stages(16, grp == n_groups - 1 ? 1 : 0, false);
+                    x_stages(z_steps, grp == n_groups - 1 ? 1 : 0, false);
 #else
-                    x_stages(16, grp == n_groups - 1 ? 1 : 0);       // last group: + lin_z.bias
+                    x_stages(z_steps, grp == n_groups - 1 ? 1 : 0);   // last group: + lin_z.bias
 #endif
                 }
             }
@@ -750,14 +791,19 @@ uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
                    int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
     Layout y;
-    if (!make_layout(*mlp, y)) return PNR_E_UNSUPPORTED;
+    const int proj = mlp->packed_texels;
+    if (!make_layout(*mlp, y, proj)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
     if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
     if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
-    if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
-    for (int i = 0; i < vw->n_levels; ++i) {
-        if (!vw->latent_packed[i]) return PNR_E_PACKED;
-        if (((uintptr_t)vw->latent_packed[i] & 15) != 0) return PNR_E_ALIGN;
-        if (vw->lat_c[i] % 16 != 0) return PNR_E_UNSUPPORTED;
+    if (proj) {      // the stream was packed for ONE view's latent map: it must be the map being rendered
+        if (vw->n_objs * vw->n_views != 1 || vw->n_levels != 1 || vw->lat_h[0] * vw->lat_w[0] != proj) return PNR_E_PACKED;
+    } else {
+        if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
+        for (int i = 0; i < vw->n_levels; ++i) {
+            if (!vw->latent_packed[i]) return PNR_E_PACKED;
+            if (((uintptr_t)vw->latent_packed[i] & 15) != 0) return PNR_E_ALIGN;
+            if (vw->lat_c[i] % 16 != 0) return PNR_E_UNSUPPORTED;
+        }
     }
     if (ws_bytes < point_mfma_workspace_bytes(mlp, vw)) return PNR_E_WORKSPACE;
     if (vw->n_views > 1 && y.nb1 == 0) return PNR_E_UNSUPPORTED;     // reduction before the first block
@@ -773,7 +819,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
     a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
     a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;
-    a.btab_floats = y.btab_floats; a.d_in = mlp->d_in;
+    a.btab_floats = y.btab_floats; a.d_in = mlp->d_in; a.proj = proj;
     a.use_code_viewdirs = prm->use_code_viewdirs; a.num_freqs = prm->num_freqs; a.freq_factor = prm->freq_factor;
     int grid = num_cus();
     if (grid > MAX_GRID) grid = MAX_GRID;
@@ -812,6 +858,46 @@ extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
     return y.total_bytes;
 }
 
+// texel count if (mlp, views) qualifies for the projected stream, else 0
+static int projectable(const pnr_mlp* mlp, const pnr_views* vw) {
+    if (!mlp || !vw || vw->n_objs * vw->n_views != 1 || vw->n_levels != 1 || !vw->latent[0]) return 0;
+    if (vw->lat_c[0] != mlp->d_latent || mlp->combine_layer < 1) return 0;
+    int T = vw->lat_h[0] * vw->lat_w[0];
+    return (T >= 4 && T <= 128) ? T : 0;
+}
+
+extern "C" uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views) {
+    Layout y;
+    int T = projectable(mlp, views);
+    if (!T || !make_layout(*mlp, y, T)) return 0;
+    return y.total_bytes;
+}
+
+extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,
+                                          uint64_t out_bytes, void* stream) {
+    if (!mlp || !views || !out) return PNR_E_NULL;
+    int T = projectable(mlp, views);
+    Layout y;
+    if (!T || !make_layout(*mlp, y, T)) return PNR_E_UNSUPPORTED;
+    if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
+    if (out_bytes < y.total_bytes) return PNR_E_WORKSPACE;
+    if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
+    if (!mlp->lin_in_w || !mlp->lin_in_b || !mlp->lin_out_w || !mlp->lin_out_b) return PNR_E_NULL;
+    for (int b = 0; b < mlp->n_blocks; ++b) {
+        if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
+        if (b < y.nb1 && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
+    }
+    float* M = (float*)((char*)out + y.btab_bytes + y.stream_bytes);
+    int64_t n_out = (int64_t)y.nb1 * HID * y.ZK;
+    hipLaunchKernelGGL(k_project_latent, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *mlp, y,
+                       views->latent[0], T, M);
+    PNR_LAUNCH_CHECK();
+    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);
+    else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
 extern "C" int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream) {
     if (!mlp || !out) return PNR_E_NULL;
     Layout y;
@@ -824,8 +910,8 @@ extern "C" int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, ui
         if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
         if (b < y.nb1 && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
     }
-    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out);
-    else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out);
+    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)nullptr);
+    else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)nullptr);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
 }

@@ -75,6 +75,9 @@ class PixelNeRFNet(torch.nn.Module):
         # bf16 and ~18 dB closer to the fp32 reference) when the shape allows, else the fp32 HIP path
         self.precision = conf.get_string("precision", os.environ.get("PNR_PRECISION", "auto"))
         self.differentiable = None      # None: follow self.training; True/False: force the taped fp32 path on/off
+        # one source view with one small latent map: stream W_z . Lat instead of W_z and skip the gather (pnr.h,
+        # pnr_pack_mlp_projected); off = always the general gather + lin_z kernel path
+        self.project_latent = conf.get_bool("project_latent", os.environ.get("PNR_PROJECT_LATENT", "1") != "0")
         self._pack_cache = {}
         self._ws = None
 
@@ -144,9 +147,11 @@ class PixelNeRFNet(torch.nn.Module):
         prm.precision = N.PRECISIONS[precision or self.resolved_precision()]
         return prm
 
-    def mlp_struct(self, mlp, precision):
+    def mlp_struct(self, mlp, precision, views=None):
         """pnr_mlp over the module's parameter storage (+ the packed MFMA stream, cached until a
-        parameter changes).  Returns (struct, keepalive)."""
+        parameter changes).  With `views` (a pnr_views of ONE view with one small latent map) the stream is the
+        projected one (lin_z pre-multiplied with the map, see pnr_pack_mlp_projected) and is also keyed by the
+        latent.  Returns (struct, keepalive)."""
         m = N.pnr_mlp()
         m.d_in, m.d_latent, m.d_hidden, m.d_out = mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out
         m.n_blocks, m.combine_layer, m.combine_type = mlp.n_blocks, mlp.combine_layer, N.COMBINE[mlp.combine_type]
@@ -166,18 +171,29 @@ class PixelNeRFNet(torch.nn.Module):
             for b, lz in enumerate(mlp.lin_z):
                 m.lin_z_w[b], m.lin_z_b[b] = P(lz.weight), P(lz.bias)
         if precision != "fp32":
-            key = ("mlp", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()))
+            proj_bytes, lat_key = 0, None
+            if views is not None and self.project_latent:
+                proj_bytes = N.lib.pnr_packed_mlp_projected_bytes(C.byref(m), C.byref(views))
+                if proj_bytes:
+                    mp = self.encoder.level_maps()[0]
+                    lat_key = (mp.data_ptr(), mp._version, tuple(mp.shape))
+            key = ("mlp", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()), lat_key)
             packed = self._pack_cache.get(key)
             if packed is None:
                 self._pack_cache = {k: v for k, v in self._pack_cache.items() if not (k[0] == "mlp" and k[1] == id(mlp))}
-                nbytes = N.lib.pnr_packed_mlp_bytes(C.byref(m))
+                nbytes = proj_bytes or N.lib.pnr_packed_mlp_bytes(C.byref(m))
                 if nbytes == 0:
                     raise ValueError("this MLP shape is not supported by the MFMA kernel; use precision='fp32'")
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=keep[0].device)
-                N.check(N.lib.pnr_pack_mlp(C.byref(m), N.PRECISIONS[precision], packed.data_ptr(), nbytes,
-                                           N.current_stream(packed.device)), "pnr_pack_mlp")
+                if proj_bytes:
+                    N.check(N.lib.pnr_pack_mlp_projected(C.byref(m), C.byref(views), N.PRECISIONS[precision], packed.data_ptr(),
+                                                         nbytes, N.current_stream(packed.device)), "pnr_pack_mlp_projected")
+                else:
+                    N.check(N.lib.pnr_pack_mlp(C.byref(m), N.PRECISIONS[precision], packed.data_ptr(), nbytes,
+                                               N.current_stream(packed.device)), "pnr_pack_mlp")
                 self._pack_cache[key] = packed
             m.packed, m.packed_bytes, m.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
+            m.packed_texels = int(views.lat_h[0] * views.lat_w[0]) if proj_bytes else 0
             keep.append(packed)
         return m, keep
 
@@ -256,8 +272,8 @@ class PixelNeRFNet(torch.nn.Module):
         dev = xyz.device
         xyz_c, vd_c = N.f32c(xyz), N.f32c(viewdirs.reshape(SB, B, 3))
         prm = self.params_struct(None, prec)
-        m, k1 = self.mlp_struct(mlp, prec)
         v, k2 = self.views_struct(prec)
+        m, k1 = self.mlp_struct(mlp, prec, v)
         if v.n_objs != SB:
             raise ValueError(f"xyz has {SB} objects but encode() saw {v.n_objs}")
         out = torch.empty(SB, B, 4, device=dev, dtype=torch.float32)

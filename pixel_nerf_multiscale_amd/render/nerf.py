@@ -157,10 +157,10 @@ class NeRFRenderer(torch.nn.Module):
         prm = net.params_struct(self, prec_c)
         prm.n_fine = Kf
         prm.n_fine_depth = int(self.n_fine_depth) if Kf > 0 else 0
-        mc, k1 = net.mlp_struct(net.mlp_coarse, prec_c)
-        fine_mod = net.mlp_fine if (Kf > 0 and net.mlp_fine is not None) else None
-        mf, k2 = net.mlp_struct(fine_mod, prec_c) if fine_mod is not None else (None, [])
         v, k3 = net.views_struct(prec_c)
+        mc, k1 = net.mlp_struct(net.mlp_coarse, prec_c, v)
+        fine_mod = net.mlp_fine if (Kf > 0 and net.mlp_fine is not None) else None
+        mf, k2 = net.mlp_struct(fine_mod, prec_c, v) if fine_mod is not None else (None, [])
         if v.n_objs != SB:
             raise ValueError(f"rays has {SB} objects but encode() saw {v.n_objs}")
         o = N.pnr_outputs()

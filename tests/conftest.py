@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The package refuses to import without its HIP library (no fallback path).  Build it when it is missing or older
+    # than its sources (hipcc cross-compiles gfx950 without a GPU); a prebuilt, current .so is left alone.
+    import __graft_entry__ as ge
+    ge._build_native_module().build(force=False, verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -212,7 +212,10 @@ def test_mfma_matches_reference(name, prec, floor_pts, floor_px):
     out = rend(net, _dev(fx["rays"]), want_weights=True)
     for lvl in ("coarse", "fine"):
         assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= floor_px, lvl
-        assert maxdiff(out[lvl].weights.cpu(), fx[f"{lvl}_weights"]) <= (0.05 if prec == "bf16" else 0.01), lvl
+        # fine pass: its sample positions are drawn from the LOW-PRECISION coarse weights/depth, so a sample can land in
+        # a neighbouring bin and move one ray's weights discontinuously (SURVEY §8c caveat) — looser bound there
+        tol_w = {("bf16", "coarse"): 0.05, ("bf16", "fine"): 0.15, ("fp16", "coarse"): 0.01, ("fp16", "fine"): 0.03}[(prec, lvl)]
+        assert maxdiff(out[lvl].weights.cpu(), fx[f"{lvl}_weights"]) <= tol_w, lvl
 
 
 @pytest.mark.parametrize("prec,floor", [("bf16", 50.0), ("fp16", 65.0)])
@@ -235,6 +238,66 @@ def test_mfma_frame_psnr(prec, floor):
         rend.forced_seed = 99
         outs[p] = rend(net, rays).coarse.rgb.cpu()
     assert _psnr(outs[prec], outs["fp32"]) >= floor
+
+
+@pytest.mark.parametrize("prec,floor,floor_self", [("bf16", 50.0, 50.0), ("fp16", 65.0, 65.0)])
+@pytest.mark.parametrize("lat,image", [((256, 8, 8), (128, 128)), ((256, 5, 7), (80, 56)), ((256, 8, 16), (128, 64))])
+def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, image):
+    """One view + one small latent map: the stream carries W_z . Lat (pnr_pack_mlp_projected) and the kernel skips the
+    gather.  Same inputs through the projected stream, the general (gather + lin_z) stream and the fp32 path; also a
+    texel count that is not a multiple of 16 (5x7) and a non-square map."""
+    import ctypes as C
+    from hip_util import build_net, build_renderer
+    import golden_util as gu
+    from pixel_nerf_multiscale_amd import _native as N
+    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=48, Kf=16, Kfd=8, lat=[lat], image=image, seed=41)
+    poses = np.stack([gu.pose_spherical(10.0, -20.0, spec["radius"])])[None]
+    W, H = image
+    g = torch.Generator().manual_seed(3)
+    tgt = gu.pose_spherical(60.0, -25.0, spec["radius"])
+    rays = torch.from_numpy(gu.pinhole_rays(tgt, W, H, spec["focal"], spec["z_near"], spec["z_far"],
+                                            torch.randperm(W * H, generator=g)[:1500].numpy()))[None].cuda()
+    outs = {}
+    for tag, p, proj in (("fp32", "fp32", False), ("proj", prec, True), ("gen", prec, False)):
+        net = build_net(spec, poses, "cuda", p)
+        net.project_latent = proj
+        if p != "fp32":
+            v, _ = net.views_struct(p)
+            m, _ = net.mlp_struct(net.mlp_coarse, p, v)
+            assert m.packed_texels == (lat[1] * lat[2] if proj else 0)
+        rend = build_renderer(spec)
+        rend.forced_seed = 7
+        rend.keep_samples = True
+        o = rend(net, rays, want_weights=True)
+        outs[tag] = o
+    for lvl in ("coarse",):        # the fine pass resamples from low-precision weights: compare the coarse pass pixel-wise
+        ref = outs["fp32"][lvl].rgb.cpu()
+        assert _psnr(outs["proj"][lvl].rgb.cpu(), ref) >= floor
+        assert _psnr(outs["gen"][lvl].rgb.cpu(), ref) >= floor
+        assert _psnr(outs["proj"][lvl].rgb.cpu(), outs["gen"][lvl].rgb.cpu()) >= floor_self
+    assert _psnr(outs["proj"].fine.rgb.cpu(), outs["fp32"].fine.rgb.cpu()) >= 36.0
+    # re-encoding (new latent) must re-pack: same weights, different map -> different output, still right
+    net = build_net(spec, poses, "cuda", prec)
+    rend = build_renderer(spec); rend.forced_seed = 7
+    a = rend(net, rays).coarse.rgb.clone()
+    net.encoder.set_latents([m * 0.5 for m in net.encoder.level_maps()])
+    b = rend(net, rays).coarse.rgb
+    net32 = build_net(spec, poses, "cuda", "fp32")
+    net32.encoder.set_latents([m * 0.5 for m in net32.encoder.level_maps()])
+    rend32 = build_renderer(spec); rend32.forced_seed = 7
+    assert _psnr(b.cpu(), rend32(net32, rays).coarse.rgb.cpu()) >= floor
+    assert float((a - b).abs().max()) > 1e-3
+    # a projected stream is tied to its map: the C ABI refuses it for other view sets
+    v, _ = net.views_struct(prec)
+    m, _ = net.mlp_struct(net.mlp_coarse, prec, v)
+    assert m.packed_texels > 0
+    prm = net.params_struct(None, prec)
+    xyz = torch.zeros(2, 8, 3, device="cuda"); out = torch.empty(2, 8, 4, device="cuda")
+    v2 = N.pnr_views.from_buffer_copy(v); v2.n_objs = 2
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = N.lib.pnr_point_mlp(C.byref(prm), C.byref(m), C.byref(v2), None, None, 0, N.ptr(xyz), N.ptr(xyz), 16, 8, N.ptr(out),
+                             ws.data_ptr(), ws.numel(), N.current_stream(xyz.device))
+    assert rc in (-6, -2, -1)
 
 
 def test_mfma_multiview_large():
