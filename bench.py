@@ -53,6 +53,18 @@ def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
     return 2 * (NS * per_view + per_pt)
 
 
+def executed_ratio(spec, net):
+    """Executed / algorithmic MFMA FLOPs per point of the fused kernel for this configuration."""
+    NS, L = spec["NS"], sum(c for c, _, _ in spec["lat"])
+    d_in = 78 if spec["use_code_viewdirs"] else 42
+    alg = flops_per_point(NS, L, d_in)
+    T = spec["lat"][0][1] * spec["lat"][0][2]
+    projected = net.project_latent and NS * spec["SB"] == 1 and len(spec["lat"]) == 1 and T <= 128
+    Lz = ((T + 15) // 16) * 16 if projected else L
+    d_pad = ((d_in + 2 + 15) // 16) * 16                      # lin_in k is padded to 16 (bias folded into 2 spare slots)
+    return flops_per_point(NS, Lz, d_pad) / alg
+
+
 def pmc_traffic_bytes(workload, precision):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC summary of THIS workload
     (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh; separate --pmc passes):
@@ -201,7 +213,11 @@ def main():
                    "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
         "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic_bytes(args.workload, args.precision),
-                     "kernel_ms": k_ms, "flops_per_launch": flops_launch},
+                     "kernel_ms": k_ms, "flops_per_launch": flops_launch,
+                     # transparency: with one source view and a small latent map the kernel evaluates lin_z as
+                     # (W_z . Lat) . w over the Hl*Wl texels (pnr_pack_mlp_projected) — fewer executed MFMA FLOPs than the
+                     # reference algorithm's count above, which is what `achieved` is priced on
+                     "executed_flops_per_launch": flops_launch * executed_ratio(spec, net)},
     }
     if rank == 0 and world == 1 and args.cpu_rays > 0:
         v, cdt, res, idx, noise = cpu_baseline(spec, args.cpu_rays, rays)

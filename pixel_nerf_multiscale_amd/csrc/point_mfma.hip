@@ -643,9 +643,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 STAMP_ACC(2, st_t);
             }
             // ---- x += lin_z[b](z)  (blocks before the view reduction only)
-            if (b < a.nb1) {
+            // one channel group / projected texels: the lin_z stages run as the prefix of the resblock's asm block below
+            if (b < a.nb1 && n_groups > 1) {
                 for (int grp = 0; grp < n_groups; ++grp) {
-                    if (n_groups > 1) gather(grp);
+                    gather(grp);
 #ifdef PNR_X_NO_ASM_LINZ
                     x_stages(z_steps, grp == n_groups - 1 ? 1 : 0, false);
 #else
@@ -660,13 +661,17 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 // hand-scheduled block (tools/gen_resblock_asm.py -> resblock_asm.inc): snapshot, fc_1-bias stage, 16 chunks
                 int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
                 const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + h * 16;
+                const uint32_t zaddr = lds_addr(zwave) + lane * 16;
+                const int cfg2z = (b < a.nb1 && n_groups == 1) ? (z_steps | (1 << 8)) : 0;      // lin_z prefix: k-steps + bias stage
                 if (DT == PNR_BF16)
                     asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
-                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x)
+                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x),
+                                   "v"(zaddr), "s"(cfg2z)
                                  : PNR_RESBLOCK_CLOBBERS);
                 else
                     asm volatile(PNR_RESBLOCK_ASM_F16 : PNR_ASM_STATE_OPERANDS
-                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x)
+                                 : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x),
+                                   "v"(zaddr), "s"(cfg2z)
                                  : PNR_RESBLOCK_CLOBBERS);
                 asm_resync(st_, li_, ls_, lr_, lw_);
             } else

@@ -12,7 +12,8 @@ Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
   * in/out scalars: %16 st_slot, %17 ld_idx, %18 ld_slot, %19 ld_rep, %20 ld_wrap   (loader cursor, see issue_piece)
   * inputs: %21 cfg = P1 | (P1+P2)<<10 | NS<<20, %22 stream base (s64), %23 ring LDS base + wave*4096 (s),
             %24 ring LDS base + lane*16 (v), %25 DMA lane offset wave*4096 + lane*16 (v),
-            %26 LDS address of fc_0.bias[block] + 16*(lane>>5) (v), %27 bias B-fragment dword 0 (v)
+            %26 LDS address of fc_0.bias[block] + 16*(lane>>5) (v), %27 bias B-fragment dword 0 (v),
+            %28 lin_z B image address (v), %29 lin_z cfg2 = n_lds | bias<<8, 0 = no lin_z prefix (s)
   * exit: all LDS reads drained, accumulators readable, 65 stages consumed, cursor advanced.
 Register use inside (all declared as clobbers): v10-13 slot read bases, v14 bias address, v15 DMA lane offset,
 v16-19 bias B fragment, v40-55 chunk accumulator (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
@@ -98,6 +99,12 @@ def gen(dt):
     e("s_addc_u32 s25, s37, 0")
     if dt == "f16":
         e("s_mov_b32 s38, 0x7bff7bff")
+    # optional prefix (%29 != 0): the block's lin_z stages 'x += M . B' + lin_z.bias, B image at %28 — one asm entry/exit
+    # and one pipeline refill less per block than a separate x-stages call
+    e("s_cmp_eq_u32 %29, 0")
+    e("s_cbranch_scc1 5f")
+    xstages_core(e, mfma, "%28", "%29")
+    e("5:")
     for k in range(4):                                       # stage k of a chunk uses slot (st_slot+1+k)&3; the bias stage = k 3
         e(f"s_add_u32 s35, s20, {1 + k}")
         e("s_and_b32 s35, s35, 3")
@@ -187,14 +194,10 @@ def gen(dt):
     return L
 
 
-def gen_xstages(dt):
-    """n_lds stages 'x[tn] += A_tn . B' with B = the k-step image [k][lane] at LDS address %26 (+1024 per stage, 16 k-steps
-    per 256-channel group -> the caller passes the address of the first k-step), then (cfg2 bit 8) one bias stage.
-    Operands: %0-%15 x tiles, %16-%20 cursor in/out (as the resblock), %21 cfg, %22 stream, %23 ring+wave*4096 (s),
-    %24 ring+lane*16 (v), %25 DMA lane offset (v), %26 B image address (v), %27 bias B dword 0 (v), %28 cfg2 = n_lds | bias<<8."""
-    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
-    L = []
-    e = L.append
+def xstages_core(e, mfma, baddr, cfg2):
+    """The stage loop of gen_xstages, entered with the cursor in s20-s29/s[24:25]/s[36:37]: n_lds = cfg2 & 0xff stages
+    with B from the LDS image at `baddr` (+1024 per stage), then (cfg2 bit 8) one bias stage with B = (%27,0,0,0).
+    Leaves s20 (st_slot) and s22 (ld_slot) advanced and masked; uses v10, v11, v14-v19, v44-v47, s34, s35, s40."""
 
     def loader_advance():
         e("s_add_u32 s21, s21, 1")
@@ -218,7 +221,7 @@ def gen_xstages(dt):
         e("s_barrier")
         for f in range(16):
             if f % 4 == 0:
-                e("s_waitcnt lgkmcnt(4)" if f else "s_waitcnt lgkmcnt(4)")
+                e("s_waitcnt lgkmcnt(4)")
             e(f"{mfma} a[{16 * f}:{16 * f + 15}], {A(f & 7)}, v[{breg}:{breg + 3}], a[{16 * f}:{16 * f + 15}]")
             base = 10 if f < 8 else 11
             e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
@@ -244,22 +247,7 @@ def gen_xstages(dt):
         e("s_lshl_b32 s35, s22, 14")
         e("s_add_u32 s40, s35, %23")                          # DMA destination of the stage being loaded
 
-    e("s_nop 15")
-    e("s_nop 15")
-    e("s_mov_b32 s39, m0")
-    e("s_mov_b32 s20, %16")
-    e("s_mov_b32 s21, %17")
-    e("s_mov_b32 s22, %18")
-    e("s_mov_b32 s23, %19")
-    e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %21, 0x3ff")
-    e("s_bfe_u32 s27, %21, 0xa000a")
-    e("s_bfe_u32 s28, %21, 0x80014")
-    e("s_mov_b64 s[36:37], %22")
-    e("s_lshl_b32 s35, s21, 14")
-    e("s_add_u32 s24, s36, s35")
-    e("s_addc_u32 s25, s37, 0")
-    e("s_and_b32 s34, %28, 0xff")                            # n_lds
+    e(f"s_and_b32 s34, {cfg2}, 0xff")                         # n_lds
     e("s_lshl_b32 s35, s20, 14")
     e("v_add_u32 v10, s35, %24")                              # cur
     e("s_add_u32 s35, s20, 1")
@@ -268,7 +256,7 @@ def gen_xstages(dt):
     e("v_add_u32 v11, s35, %24")                              # nxt
     e("s_lshl_b32 s35, s22, 14")
     e("s_add_u32 s40, s35, %23")
-    e("v_mov_b32 v14, %26")
+    e(f"v_mov_b32 v14, {baddr}")
     e("v_mov_b32 v15, %25")
     e("ds_read_b128 v[16:19], v14")                           # B of the first k-step
     e("v_add_u32 v14, 0x400, v14")
@@ -291,7 +279,7 @@ def gen_xstages(dt):
     e("s_cmp_lg_u32 s34, 0")
     e("s_cbranch_scc1 1b")
     e("3:")
-    e("s_bitcmp1_b32 %28, 8")                                 # bias stage requested?
+    e(f"s_bitcmp1_b32 {cfg2}, 8")                             # bias stage requested?
     e("s_cbranch_scc0 4f")
     e("v_mov_b32 v16, %27")
     e("v_mov_b32 v17, 0")
@@ -301,6 +289,32 @@ def gen_xstages(dt):
     stage_body(16)
     advance_slots()
     e("4:")
+
+
+def gen_xstages(dt):
+    """n_lds stages 'x[tn] += A_tn . B' with B = the k-step image [k][lane] at LDS address %26 (+1024 per stage, 16 k-steps
+    per 256-channel group -> the caller passes the address of the first k-step), then (cfg2 bit 8) one bias stage.
+    Operands: %0-%15 x tiles, %16-%20 cursor in/out (as the resblock), %21 cfg, %22 stream, %23 ring+wave*4096 (s),
+    %24 ring+lane*16 (v), %25 DMA lane offset (v), %26 B image address (v), %27 bias B dword 0 (v), %28 cfg2 = n_lds | bias<<8."""
+    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
+    L = []
+    e = L.append
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b32 s39, m0")
+    e("s_mov_b32 s20, %16")
+    e("s_mov_b32 s21, %17")
+    e("s_mov_b32 s22, %18")
+    e("s_mov_b32 s23, %19")
+    e("s_mov_b32 s29, %20")
+    e("s_and_b32 s26, %21, 0x3ff")
+    e("s_bfe_u32 s27, %21, 0xa000a")
+    e("s_bfe_u32 s28, %21, 0x80014")
+    e("s_mov_b64 s[36:37], %22")
+    e("s_lshl_b32 s35, s21, 14")
+    e("s_add_u32 s24, s36, s35")
+    e("s_addc_u32 s25, s37, 0")
+    xstages_core(e, mfma, "%26", "%28")
     e("s_waitcnt lgkmcnt(0)")
     e("s_nop 15")
     e("s_nop 15")
