@@ -76,3 +76,46 @@ class ShardedRenderer:
             full = pix
         full = full[:B]
         return full[:, :3].reshape(1, B, 3), full[:, 3].reshape(1, B)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Data-parallel training (SURVEY §8 N4 + e): every rank renders + back-propagates its own ray batch through the
+# HIP backward kernels (render/autograd.py); gradients are averaged with ONE all-reduce per bucket over RCCL.
+# The reference has no multi-GPU training path at all (its DataParallel wrapper is eval-only and broken, D8).
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
+    """Average .grad of `params` over the ranks of `group`: gradients are packed into flat fp32 buckets of at most
+    bucket_bytes (xGMI rings are per-link bound: few large messages beat many small ones), all-reduced in place and
+    copied back.  Parameters without a gradient on this rank contribute zeros (every rank must see the same list).
+    Returns the number of collectives issued."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_coll, i = 0, 0
+    while i < len(params):
+        j, n = i, 0
+        while j < len(params) and (j == i or (n + params[j].numel()) * 4 <= bucket_bytes):
+            n += params[j].numel()
+            j += 1
+        dev = params[i].device
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params[i:j]:
+            if p.grad is not None:
+                flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            n_coll += 1
+            if average:
+                flat.div_(world)
+        off = 0
+        for p in params[i:j]:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+        i = j
+    return n_coll

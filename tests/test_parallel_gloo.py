@@ -85,3 +85,44 @@ def test_single_process_passthrough():
     rgb, depth = sr(rays)
     ref = fake_render(rays, 0, frame_seed(3, 0))
     assert torch.equal(rgb, ref[0]) and torch.equal(depth, ref[1])
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pixel_nerf_multiscale_amd.parallel import allreduce_gradients
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
+                  torch.nn.Parameter(torch.zeros(2, 2), requires_grad=False), torch.nn.Parameter(torch.zeros(4))]
+        params[0].grad = torch.full((5, 3), float(rank + 1))
+        params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+        if rank == 0:
+            params[3].grad = torch.ones(4)                 # missing on the other ranks: counts as zeros
+        n = allreduce_gradients(params, bucket_bytes=64)   # tiny buckets: several collectives
+        q.put((rank, n, [None if p.grad is None else p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_gradients_averages_over_ranks(world):
+    """Data-parallel training step: per-rank gradients from the HIP backward are averaged in flat buckets."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mean_scale = sum(range(1, world + 1)) / world
+    for rank, n, grads in res:
+        assert n >= 2
+        assert (grads[0] == mean_scale).all()
+        assert torch.allclose(torch.from_numpy(grads[1]), torch.arange(7, dtype=torch.float32) * mean_scale)
+        assert grads[2] is None
+        assert torch.allclose(torch.from_numpy(grads[3]), torch.full((4,), 1.0 / world))
