@@ -321,6 +321,165 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
     if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
 }
 
+// ------------------------------------------------------------------ bf16 MFMA GEMM on the fp32 tape (opt-in, AMP-like)
+// Same contract and operand forms as k_mgemm_f32, but the products run on v_mfma_f32_32x32x16_bf16: operands are
+// converted fp32 -> bf16 while they are staged into LDS (the tape, the weights and every result stay fp32 in
+// memory, accumulation is fp32).  The reference's counterpart is its AMP switch (train/train.py:385-398).
+// 128x128 tile, 32-deep reduction tiles, LDS image [row][32 k] bf16 with 80-byte rows (conflict-free
+// ds_read_b128 fragment reads: lane = (row l%32, k-half l/32) takes 8 consecutive k).  Operands stored
+// reduction-major are transposed in registers: a thread owns a 4(r) x 4(x) block and writes 4 x 8 bytes.
+// Requirements (else the caller uses k_mgemm_f32): 16-byte aligned operands, leading dimensions % 4 == 0,
+// the reduction extent % 32 == 0 unless SPLIT (whose row tail is zero-filled), x extents % 4 == 0.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2v f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2v));
+}
+
+template <bool RC>
+__device__ __forceinline__ void mh_fetch(const float* __restrict__ S, int ld, int x0, int X, int r0, int r1, float4 (&v)[4]) {
+    const int t = threadIdx.x;
+    if (RC) {            // stored (X, R): thread -> row t/2, 16 consecutive r at 16*(t&1)
+        const int x = min(x0 + (t >> 1), X - 1);
+        const float* p = S + (size_t)x * ld + r0 + 16 * (t & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const float4*)(p + 4 * i);
+    } else {             // stored (R, X): thread -> 4 r's at 4*(t&7), 4 x's at 4*(t>>3)
+        const int x = min(x0 + 4 * (t >> 3), X - 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r0 + 4 * (t & 7) + i, r1 - 1);
+            v[i] = *(const float4*)(S + (size_t)r * ld + x);
+        }
+    }
+}
+
+template <bool RC, bool RELU, bool ZERO_TAIL>
+__device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int r0, int r1) {
+    const int t = threadIdx.x;
+    // the loads above are unconditional and complete HERE (not earlier: hipcc would otherwise sink them into the
+    // tail predicate and wait on each one)
+    asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
+                      "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
+    float f[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                   v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+    if (RELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    if (RC) {
+        if (ZERO_TAIL) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f[e] = (r0 + 16 * (t & 1) + e < r1) ? f[e] : 0.f;
+        }
+        uint4 lo = {pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
+        uint4 hi = {pk_bf16(f[8], f[9]), pk_bf16(f[10], f[11]), pk_bf16(f[12], f[13]), pk_bf16(f[14], f[15])};
+        *(uint4*)&T[t >> 1][16 * (t & 1)] = lo;
+        *(uint4*)&T[t >> 1][16 * (t & 1) + 8] = hi;
+    } else {
+        if (ZERO_TAIL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[4 * i + e] = (r0 + 4 * (t & 7) + i < r1) ? f[4 * i + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {        // element (r = 4*(t&7)+i, x = 4*(t>>3)+e) is f[4 i + e]
+            uint2 w = {pk_bf16(f[e], f[4 + e]), pk_bf16(f[8 + e], f[12 + e])};
+            *(uint2*)&T[4 * (t >> 3) + e][4 * (t & 7)] = w;
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
+static __global__ void __launch_bounds__(256) k_mgemm_bf16(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
+    int M, int N, int Rn, int r_per_split) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float4 va[4], vb[4];
+    float rs = 0.f;
+    mh_fetch<A_RC>(A, lda, m0, M, rb, re, va);
+    mh_fetch<B_RC>(B, ldb, n0, N, rb, re, vb);
+    mh_stage<A_RC, RELU_A, SPLIT>(As[0], va, rb, re);
+    mh_stage<B_RC, RELU_B, false>(Bs[0], vb, rb, re);
+    if (rb + 32 < re) {
+        mh_fetch<A_RC>(A, lda, m0, M, rb + 32, re, va);
+        mh_fetch<B_RC>(B, ldb, n0, N, rb + 32, re, vb);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = rb; r0 < re; r0 += 32) {
+        if (r0 + 32 < re) {
+            mh_stage<A_RC, RELU_A, SPLIT>(As[buf ^ 1], va, r0 + 32, re);
+            mh_stage<B_RC, RELU_B, false>(Bs[buf ^ 1], vb, r0 + 32, re);
+            if (r0 + 64 < re) {
+                mh_fetch<A_RC>(A, lda, m0, M, r0 + 64, re, va);
+                mh_fetch<B_RC>(B, ldb, n0, N, r0 + 64, re, vb);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a0 = *(const bf16x8*)&As[buf][wm + lc][16 * s + 8 * lr];
+            bf16x8 a1 = *(const bf16x8*)&As[buf][wm + 32 + lc][16 * s + 8 * lr];
+            bf16x8 b0 = *(const bf16x8*)&Bs[buf][wn + lc][16 * s + 8 * lr];
+            bf16x8 b1 = *(const bf16x8*)&Bs[buf][wn + 32 + lc][16 * s + 8 * lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (rowsum && blockIdx.y == 0 && t < 128) {       // bias gradient = row sums of the (bf16-rounded) A tile
+#pragma unroll
+            for (int r = 0; r < 32; r += 2) {
+                uint32_t p = *(const uint32_t*)&As[buf][t][r];
+                rs += __builtin_bit_cast(float, p << 16) + __builtin_bit_cast(float, p & 0xffff0000u);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lc;
+            if (n >= N) continue;
+            const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bn;
+                if (SPLIT) {
+                    atomicAdd(C + (size_t)m * ldc + n, v);
+                } else {
+                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
+                    if (R) v += R[(size_t)m * ldr + n];
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+        }
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+}
+
 // dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4): one thread per k
 // column walks a slice of the rows (X read once, coalesced; dY rows broadcast).  HBM-bound: 4 K bytes per row.
 template <bool RELU_X>
@@ -625,10 +784,19 @@ static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
     return ((((uintptr_t)A & 15) == 0 && lda % 4 == 0) ? 1 : 0) | ((((uintptr_t)B & 15) == 0 && ldb % 4 == 0) ? 2 : 0);
 }
 
+static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0; }
+
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
-                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
+                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, bool half = false) {
     if (M == 0) return PNR_OK;
+    if (half && N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(X, ldx) && al16(W, ldw)) {
+        dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+        hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
+                           Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     if (N >= 32 && K >= 16) {       // MFMA tile kernel; the skinny heads (N = 4, K = 4) stay on the FMA kernel
         dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
         hipLaunchKernelGGL((k_mgemm_f32<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
@@ -646,8 +814,17 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
 // dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
-                      int N, int K, hipStream_t s) {
+                      int N, int K, hipStream_t s, bool half = false) {
     if (!dW || M == 0) return PNR_OK;
+    if (half && N >= 32 && K >= 32 && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx)) {
+        const int rows = 1024;
+        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));
+        hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                           (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
+                           N, K, (int)M, rows);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     if (N >= 32 && K >= 32) {
         // dW = A B with A(n, r = m) = dY[m][n] and B(r = m, k) = act(X[m][k]): both stored reduction-major
         const int rows = 1024;
@@ -685,13 +862,14 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
+    const bool half = prm->precision == PNR_BF16;       // bf16 MFMA products on the fp32 tape (k_mgemm_bf16)
     int64_t tot = MV * (L + Din);
     hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
                        (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
-    PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, x0, H, MV, H, Din, s)));
+    PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, x0, H, MV, H, Din, s, half)));
     auto combine = [&](float* dst) -> int32_t {
         int64_t per_view = P * H;
         hipLaunchKernelGGL(k_combine_f32, dim3((unsigned)((per_view + 255) / 256)), dim3(256), 0, s, t.xpre, NS,
@@ -703,14 +881,14 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     for (int b = 0; b < nb; ++b) {
         const int64_t M = t.rows[b];
         if (L > 0 && b < n_lin_z)
-            PNR_TRY((gemm<false, false>(t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], t.A[b], H, nullptr, 0, t.A[b], H, M, H, L, s)));
-        PNR_TRY((gemm<true, false>(t.A[b], H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0, nullptr, 0, t.h[b], H, M, H, H, s)));
+            PNR_TRY((gemm<false, false>(t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], t.A[b], H, nullptr, 0, t.A[b], H, M, H, L, s, half)));
+        PNR_TRY((gemm<true, false>(t.A[b], H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0, nullptr, 0, t.h[b], H, M, H, H, s, half)));
         const bool comb = NS > 1 && b + 1 == cl;
         float* dst = comb ? t.xpre : t.A[b + 1];
-        PNR_TRY((gemm<true, false>(t.h[b], H, mlp->fc1_w[b], H, mlp->fc1_b[b], t.A[b], H, nullptr, 0, dst, H, M, H, H, s)));
+        PNR_TRY((gemm<true, false>(t.h[b], H, mlp->fc1_w[b], H, mlp->fc1_b[b], t.A[b], H, nullptr, 0, dst, H, M, H, H, s, half)));
         if (comb) PNR_TRY(combine(t.A[b + 1]));
     }
-    PNR_TRY((gemm<true, false>(t.A[nb], H, mlp->lin_out_w, H, mlp->lin_out_b, nullptr, 0, nullptr, 0, t.o4, 4, P, 4, H, s)));
+    PNR_TRY((gemm<true, false>(t.A[nb], H, mlp->lin_out_w, H, mlp->lin_out_b, nullptr, 0, nullptr, 0, t.o4, 4, P, 4, H, s, half)));
     hipLaunchKernelGGL(k_out_act, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, t.o4, P, out);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
@@ -729,6 +907,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     Tape t = carve_tape(mlp, vw, P, tape);
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
+    const bool half = prm->precision == PNR_BF16;
     uint8_t* wp = (uint8_t*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     float* dx = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
     float* dx2 = (float*)wp;               wp += a256((uint64_t)MV * H * 4);
@@ -744,20 +923,20 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     hipLaunchKernelGGL(k_out_act_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (const float4*)out,
                        (const float4*)d_out, P, (float4*)do4);
     PNR_LAUNCH_CHECK();
-    PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s)));
-    PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s)));
+    PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s, half)));
+    PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s, half)));
     bool dz_started = false;
     for (int b = nb - 1; b >= 0; --b) {
         const int64_t M = t.rows[b];
-        PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s)));
-        PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s)));
-        PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s)));
-        PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s)));
+        PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half)));
+        PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s, half)));
+        PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half)));
+        PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half)));
         if (L > 0 && b < n_lin_z) {
-            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s)));
+            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half)));
             if (want_dz) {
                 PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
-                                           dzx, E, M, L, H, s)));
+                                           dzx, E, M, L, H, s, half)));
                 dz_started = true;
             }
         }
@@ -769,10 +948,10 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
             float* tmp = dx; dx = dx2; dx2 = tmp;
         }
     }
-    PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s)));
+    PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s, half)));
     if ((want_p || want_lat) && L > 0 && !dz_started) PNR_HIP_CHECK(hipMemsetAsync(dzx, 0, (size_t)MV * E * 4, s));
     if (want_p)
-        PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s)));
+        PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s, half)));
     if (want_p || (want_lat && L > 0)) {
         hipLaunchKernelGGL(k_features_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, *vw, src, P, pts_per_obj, L, Din,
                            prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, E, lg, d_xyz, d_z);

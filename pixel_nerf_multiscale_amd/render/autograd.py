@@ -11,7 +11,9 @@ points (csrc/train_f32.hip) — no PyTorch arithmetic on the per-point data:
 
 Gradients reach the MLP weights, the encoder's latent maps (and through them the ResNet trunk, which stays
 a PyTorch module) and — because nerf.py:287-289 does not detach the depth-guided samples — the coarse depth
-through the fine pass's sample positions.  Arithmetic is fp32 (the reference trains in fp32).
+through the fine pass's sample positions.  Arithmetic is fp32 (the reference trains in fp32);
+`net.train_precision = "bf16"` runs the GEMM products on the bf16 MFMA with fp32 accumulation, fp32 tape and fp32
+results (the counterpart of the reference's AMP switch, train/train.py:385-398).
 """
 import ctypes as C
 
@@ -199,7 +201,7 @@ def _header(net, mlp, rays_mode):
     return dict(d_in=mlp.d_in, d_latent=mlp.d_latent, d_hidden=mlp.d_hidden, d_out=mlp.d_out, n_blocks=mlp.n_blocks,
                 combine_layer=mlp.combine_layer, combine_type=mlp.combine_type,
                 n_lin_z=len(mlp.lin_z) if mlp.d_latent else 0, n_params=len(mlp_tensors(mlp)),
-                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=net.params_struct(None, "fp32"))
+                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=net.params_struct(None, net.train_precision))
 
 
 def point_mlp_rays(net, mlp, rays, z):

@@ -206,3 +206,45 @@ def test_training_abi_error_codes_and_empty_batch():
     assert N.lib.pnr_point_mlp_train_fwd(C.byref(prm), C.byref(m), C.byref(v), N.ptr(rays), N.ptr(z), K, None, None, 0, 1,
                                          N.ptr(out), None, 0, s) in (0, -2)               # empty batch: no launch
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name", ["full_ns1", "full_ns3", "full_multiscale_ns2", "tiny_ns2_codeview"])
+def test_bf16_product_mode_gradients(name):
+    """train_precision='bf16': GEMM products on the bf16 MFMA (fp32 accumulate, fp32 tape).  No reference numerics exist
+    for it (the reference's AMP is fp16 autocast), so the bound is against the fp32 path on the same inputs.  Rounding
+    28 chained GEMMs of a 5-block ReLU net to 8 mantissa bits moves each gradient tensor by 5-8 % in l2 on these
+    256-point batches (a CPU emulation that rounds only the FORWARD operands already moves them by 8-10 % on the
+    unmodified fixtures, whose sigma head is scaled x20 — removed here); a wrong operand layout would give cosine ~ 0."""
+
+    def run(prec):
+        fx, spec, net, rend = hu.setup(name)
+        net.train()
+        net.train_precision = prec
+        with torch.no_grad():
+            for m in (net.mlp_coarse, net.mlp_fine):
+                if m is not None:
+                    m.lin_out.weight[3] /= 20.0
+                    m.lin_out.bias[3] = (m.lin_out.bias[3] - 4.0) / 20.0 + 1.0
+        maps = [torch.from_numpy(x).cuda().requires_grad_(True) for x in gu.make_latents(spec)]
+        net.encoder.set_latents(maps)
+        out = rend(net, torch.from_numpy(fx["rays"]).cuda(), want_weights=True)
+        G = {k: torch.from_numpy(v).cuda() for k, v in gu.make_loss_weights(spec).items()}
+        # coarse pass only: the fine pass resamples from low-precision weights (discontinuous)
+        loss = (out.coarse.rgb * G["coarse_rgb"]).sum() + (out.coarse.weights * G["coarse_weights"]).sum()
+        loss.backward()
+        grads = {"coarse." + k: p.grad.clone() for k, p in net.mlp_coarse.named_parameters()}
+        grads.update({f"latent.{i}": m.grad.clone() for i, m in enumerate(maps)})
+        return out.coarse.rgb.detach().clone(), grads
+
+    rgb32, g32 = run("fp32")
+    rgb16, g16 = run("bf16")
+    assert float((rgb32 - rgb16).abs().max()) <= 1e-2
+    assert float(((rgb32 - rgb16) ** 2).mean()) <= 1e-5           # >= 50 dB
+    for k in g32:
+        a, b = g16[k].double().flatten(), g32[k].double().flatten()
+        nb = float(b.norm())
+        if nb == 0:
+            continue
+        rel = float((a - b).norm()) / nb
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert rel <= 0.15 and cos >= 0.99, (k, rel, cos)
