@@ -215,8 +215,16 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
                     if (h == 0 && j == 0) val = bp[n];
                     else if (h == 0 && j == 1) val = bp[n] - Num<DT>::back(Num<DT>::cvt(bp[n]));
                 } else {
+                    // 64 chunk stages in the kernel's software-pipelined order: F(0) | F(1) G(0) | ... | F(15) G(14) | G(15),
+                    // F(c) = the 2 fc_0 stages of chunk c (parts 0,1), G(c) = its 2 fc_1 stages (parts 2,3)
                     int q = in_blk - (y.SZ + 2);        // 0..63
-                    int c = q >> 2, part = q & 3;
+                    int c, part;
+                    if (q < 2) { c = 0; part = q; }
+                    else if (q >= 62) { c = 15; part = 2 + (q - 62); }
+                    else {
+                        int jq = q - 2, cc = jq >> 2, pp = jq & 3;
+                        if (pp < 2) { c = cc + 1; part = pp; } else { c = cc; part = pp; }
+                    }
                     if (part < 2) {                     // fc_0 chunk c: rows 32c.., k tiles t = 8*part + f/2
                         int t = 8 * part + (f >> 1), sk = f & 1;
                         val = m.fc0_w[b][(size_t)(32 * c + r) * HID + 32 * t + perm_k(sk, h, j)];
@@ -682,10 +690,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             x_stages(0, 1);                       // + fc_1.bias
             STAMP_ACC(5, st_t);
             {
-                f32x16 hacc = load_hbias(b, 0);
+                // same stage order as the asm block: F(0) | F(c+1) G(c) ... | G(15)
+                f32x16 hacc = chunk_from_xb(load_hbias(b, 0));
 #pragma unroll 1
                 for (int c = 0; c < 16; ++c) {
-                    hacc = chunk_from_xb(hacc);
+                    f32x16 hnext = hacc;
+                    if (c < 15) hnext = chunk_from_xb(load_hbias(b, c + 1));
                     frag_t hb[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -694,7 +704,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         hb[s].z = NM::sat(relu_pk(NM::pack(hacc[8 * s + 4], hacc[8 * s + 5])));
                         hb[s].w = NM::sat(relu_pk(NM::pack(hacc[8 * s + 6], hacc[8 * s + 7])));
                     }
-                    hacc = load_hbias(b, (c + 1) & 15);          // next chunk's bias while fc_1 runs
+                    hacc = hnext;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         begin_stage();

@@ -16,7 +16,7 @@ Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
             %28 lin_z B image address (v), %29 lin_z cfg2 = n_lds | bias<<8, 0 = no lin_z prefix (s)
   * exit: all LDS reads drained, accumulators readable, 65 stages consumed, cursor advanced.
 Register use inside (all declared as clobbers): v10-13 slot read bases, v14 bias address, v15 DMA lane offset,
-v16-19 bias B fragment, v40-55 chunk accumulator (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
+v16-19 bias B fragment, v40-55 and v72-87 the two chunk accumulators (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
 v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 tiles x 2 k-steps x 4), s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
 """
 import os
@@ -140,44 +140,92 @@ def gen(dt):
         refill(f, 3)
         dma(f, 3)
 
-    # ---------------------------------------------------------------- 16 chunks
-    e("s_mov_b32 s34, 16")
-    e("1:")
-    for half in range(2):                                    # fc_0: chunk accumulator v[40:55] += W0[chunk] . relu(x)
-        k = half
+    # ---------------------------------------------------------------- 16 chunks, software-pipelined
+    # Stage order of a block (the packer follows it, k_pack_mlp): bias | F(0) | F(1) G(0) | F(2) G(1) | ... | F(15) G(14) | G(15)
+    # with F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[c] . relu(x)) and G(c) = its 2 fc_1 stages
+    # (x += W1[:, c] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
+    # other — finished 32 MFMAs earlier — is converted to relu(h_c) in the MFMA gaps and reloaded with the fc_0.bias
+    # rows of chunk c+2, so no MFMA waits for a conversion and no s_nop pads the chain's tail.
+    # Stage index i within the block (bias stage = 0) consumes ring slot (st_slot + i) & 3: refill/dma position k = (i-1) & 3.
+    ACC = (40, 72)
+
+    def fc0_stage(acc, i, half, hook=None, first_wait=4):
+        k = (i - 1) & 3
         begin_stage()
         for f in range(16):
             if f % 4 == 0:
-                e("s_waitcnt lgkmcnt(4)")                  # (the fc_0.bias loads are older than every fragment load waited for here)
-            e(f"{mfma} v[40:55], {A(f & 7)}, {XB(8 * half + (f >> 1), f & 1)}, v[40:55]")
+                e(f"s_waitcnt lgkmcnt({first_wait if f == 0 else 4})")
+            e(f"{mfma} v[{acc}:{acc + 15}], {A(f & 7)}, {XB(8 * half + (f >> 1), f & 1)}, v[{acc}:{acc + 15}]")
             refill(f, k)
             dma(f, k)
-    begin_stage()                                            # fc_1 stage 0's wait + barrier, under the chain's tail
-    e("s_nop 15")
-    e("s_nop 7")
-    for i in range(8):                                       # relu(h) -> two B fragments
-        e(f"{cvt} v{60 + i}, v{40 + 2 * i}, v{41 + 2 * i}")
-        e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
-        if dt == "f16":
-            e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
-    for q in range(4):                                       # next chunk's fc_0.bias rows
-        e(f"ds_read_b128 v[{40 + 4 * q}:{43 + 4 * q}], v14 offset:{32 * q}")
-    e("v_add_u32 v14, 0x80, v14")
-    for half in range(2):                                    # fc_1: x[tn] += W1[tn, chunk] . relu(h)
-        k = 2 + half
-        if half == 1:
-            begin_stage()
+            if hook:
+                hook(f)
+
+    def fc1_stage(i, half, first_wait=4):
+        k = (i - 1) & 3
+        begin_stage()
         for f in range(16):
             tn = 8 * half + (f >> 1)
             if f % 4 == 0:
-                # the 4 bias loads issued above are younger than fragments 0..7 of this stage: allow 8 outstanding there
-                e("s_waitcnt lgkmcnt(8)" if (half == 0 and f == 0) else "s_waitcnt lgkmcnt(4)")
+                e(f"s_waitcnt lgkmcnt({first_wait if f == 0 else 4})")
             e(f"{mfma} a[{16 * tn}:{16 * tn + 15}], {A(f & 7)}, v[{60 + 4 * (f & 1)}:{63 + 4 * (f & 1)}], a[{16 * tn}:{16 * tn + 15}]")
             refill(f, k)
             dma(f, k)
+
+    def convert_hook(acc, reload):
+        """relu(h) of the finished accumulator -> v60-67, one register per MFMA gap (gaps 2..9); then (gap 15) the next
+        fc_0.bias rows into it.  The 4 bias loads are younger than that stage's refills: the next stage's first wait
+        allows 8 outstanding."""
+        def hook(f):
+            if 2 <= f <= 9:
+                i = f - 2
+                e(f"{cvt} v{60 + i}, v{acc + 2 * i}, v{acc + 2 * i + 1}")
+                e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
+                if dt == "f16":
+                    e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
+            if f == 15 and reload:
+                for q in range(4):
+                    e(f"ds_read_b128 v[{acc + 4 * q}:{acc + 4 * q + 3}], v14 offset:{32 * q}")
+                e("v_add_u32 v14, 0x80, v14")
+        return hook
+
+    def body(c_parity, i0, reload=True):
+        """F(c+1) into ACC[1-c_parity] with the conversion of ACC[c_parity] riding in its first stage, then G(c)."""
+        fc0_stage(ACC[1 - c_parity], i0, 0, hook=convert_hook(ACC[c_parity], reload))
+        fc0_stage(ACC[1 - c_parity], i0 + 1, 1, first_wait=8 if reload else 4)
+        fc1_stage(i0 + 2, 0)
+        fc1_stage(i0 + 3, 1)
+
+    # chunk 1's fc_0.bias rows into the second accumulator (chunk 0's went into v40-55 in the setup)
+    for q in range(4):
+        e(f"ds_read_b128 v[{72 + 4 * q}:{75 + 4 * q}], v14 offset:{32 * q}")
+    e("v_add_u32 v14, 0x80, v14")
+    fc0_stage(ACC[0], 1, 0, first_wait=8)                     # F(0): stage indices 1, 2 (the 4 loads above are younger than its fragments)
+    fc0_stage(ACC[0], 2, 1)
+    e("s_mov_b32 s34, 7")
+    e("1:")
+    body(0, 3)                                               # c even:  F(c+1) on v72.., h_c from v40..
+    body(1, 3)                                               # c odd :  F(c+1) on v40.., h_c from v72..  (stage positions repeat mod 4)
     e("s_sub_u32 s34, s34, 1")
     e("s_cmp_lg_u32 s34, 0")
     e("s_cbranch_scc1 1b")
+    body(0, 3, reload=False)                                 # c = 14: F(15) on v72.., no chunk 16 to preload
+    # G(15): convert v72.. (its chain's last MFMA is 32 MFMAs back), then the last two fc_1 stages
+    begin_stage()
+    for i in range(8):
+        e(f"{cvt} v{60 + i}, v{72 + 2 * i}, v{73 + 2 * i}")
+        e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
+        if dt == "f16":
+            e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
+    k = (63 - 1) & 3
+    for f in range(16):
+        tn = f >> 1
+        if f % 4 == 0:
+            e("s_waitcnt lgkmcnt(4)")
+        e(f"{mfma} a[{16 * tn}:{16 * tn + 15}], {A(f & 7)}, v[{60 + 4 * (f & 1)}:{63 + 4 * (f & 1)}], a[{16 * tn}:{16 * tn + 15}]")
+        refill(f, k)
+        dma(f, k)
+    fc1_stage(64, 1)
 
     # ---------------------------------------------------------------- exit
     e("s_waitcnt lgkmcnt(0)")
@@ -418,7 +466,7 @@ def main():
             for l in lines:
                 f.write(f'    "{l}\\n\\t" \\\n')
             f.write('    ""\n\n')
-        clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 20)) + list(range(40, 56)) + list(range(60, 72)) + list(range(96, 256))] \
+        clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 20)) + list(range(40, 56)) + list(range(60, 88)) + list(range(96, 256))] \
             + [f"s{i}" for i in list(range(20, 32)) + list(range(33, 44))]
         f.write("#define PNR_RESBLOCK_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
     # audit: every physical v/s register the text names must be declared clobbered (operands are %N references)
