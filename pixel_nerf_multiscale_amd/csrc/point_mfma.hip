@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t p) {
 // stream then carries the (512 x T) products M_b = W_z,b . Lat in place of W_z,b: ceil(T/16) k-steps instead of L/16,
 // and the per-point latent gather disappears (the B operand is the tap-weight image).
 struct Layout {
-    int d_in, d_in_pad, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK;
+    int d_in, d_in_pad, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK;
     uint64_t btab_bytes, stream_bytes, total_bytes, proj_bytes;
 };
 static constexpr int BLOCK_STAGES = 1 + 16 * 4;
@@ -119,10 +119,14 @@ static constexpr int BLOCK_STAGES = 1 + 16 * 4;
 __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0) {
     if (m.d_hidden != HID || m.d_out != 4 || m.d_latent <= 0 || (m.d_latent % 256) != 0 || m.d_latent > 1024) return false;
     if (m.n_blocks < 1 || m.n_blocks > PNR_MAX_BLOCKS || m.d_in < 1 || m.d_in > 78) return false;
+    // LIN_IN k layout (chosen for the kernel, see the prologue): lane half h of k-step s, element j holds slot 8 s + j of
+    //   [ sin(f_q v_i + h pi/2): q = 0..5, i = 0..D-1 | raw_t: t = 0..2 (h = 0: x_rot, h = 1: rotated view dir) | 1.0 | 0.. ]
+    // with D = 3 (code over xyz, d_in 42) or 6 (code over xyz + dirs, d_in 78); 6 frequencies only.
     y.d_in = m.d_in;
-    y.d_in_pad = ((m.d_in + 2 + 15) / 16) * 16;     // two spare k-slots carry the folded lin_in bias (hi, lo)
-    y.S_in = y.d_in_pad / 16;
-    if (y.S_in > 5) return false;
+    if (m.d_in != 42 && m.d_in != 78) return false;
+    y.D = m.d_in == 78 ? 6 : 3;
+    y.S_in = (6 * y.D + 4 + 7) / 8;                  // 3 or 5 k-steps
+    y.d_in_pad = 16 * y.S_in;
     y.L = m.d_latent;
     if (proj_T < 0 || proj_T > 128) return false;
     y.proj_T = proj_T;
@@ -183,11 +187,18 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
         // ---- locate the stage
         int s = stage;
         bool done = false;
-        if (s < y.S_in) {                               // LIN_IN: natural k, bias folded at k = d_in (hi), d_in+1 (lo)
-            int n = 32 * f + r, k = 16 * s + 8 * h + j;
-            if (k < m.d_in) val = m.lin_in_w[(size_t)n * m.d_in + k];
-            else if (k == m.d_in) val = m.lin_in_b[n];
-            else if (k == m.d_in + 1) val = m.lin_in_b[n] - Num<DT>::back(Num<DT>::cvt(m.lin_in_b[n]));
+        if (s < y.S_in) {                               // LIN_IN: slot layout of make_layout, bias folded into slot 6D+3 (h=0: hi, h=1: lo)
+            const int n = 32 * f + r, idx = 8 * s + j, D = y.D;
+            if (idx < 6 * D) {
+                const int q = idx / D, i = idx % D;
+                val = m.lin_in_w[(size_t)n * m.d_in + D + (2 * q + h) * D + i];      // code.py: [x, sin f0, cos f0, sin f1, ...]
+            } else if (idx < 6 * D + 3) {
+                const int t = idx - 6 * D;
+                const int col = h == 0 ? t : (D == 3 ? 3 + 12 * D + t : 3 + t);         // h=1: view dirs (raw or coded inputs 3..5)
+                val = m.lin_in_w[(size_t)n * m.d_in + col];
+            } else if (idx == 6 * D + 3) {
+                val = h == 0 ? m.lin_in_b[n] : m.lin_in_b[n] - Num<DT>::back(Num<DT>::cvt(m.lin_in_b[n]));
+            }
             done = true;
         } else s -= y.S_in;
         int b = 0;
@@ -607,30 +618,37 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 rot3(cam.R, p, xr);
                 rot3(cam.R, d, dr);
                 project(cam, xr, pu, pv);
-                // ---- positional features -> wave-private LDS image [k-step][half][col][8] (16-bit), natural k.
-                //      Lane half h writes the phase-h terms (sin for h=0, sin(.+pi/2) for h=1): uniform code.
+                // ---- positional features -> wave-private LDS image [k-step][lane][8] (16-bit) in the slot layout of
+                //      make_layout: every lane builds its own 8 entries per k-step (uniform code: lane half h takes the
+                //      phase-h sines, h=0 the raw x_rot, h=1 the rotated view dir) and stores them with one ds_write_b128.
                 {
-                    uint16_t* fz = (uint16_t*)zwave;
-                    for (int i = lane; i < 5 * 64 * 4; i += 64) ((uint32_t*)zwave)[i] = 0u;     // 5 KiB
-                    const int dcode = a.use_code_viewdirs ? 6 : 3;
-                    auto put = [&](int k, float val) {
-                        fz[(((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + r) * 8 + (k & 7)] = NM::cvt(val);
-                    };
                     const float ph = h ? 1.57079637f : 0.0f;
-                    for (int i = 0; i < dcode; ++i) {
-                        const float xi = i == 0 ? xr[0] : i == 1 ? xr[1] : i == 2 ? xr[2] : i == 3 ? dr[0] : i == 4 ? dr[1] : dr[2];
-                        if (h == 0) put(i, xi);
-                        float f = a.freq_factor;
-                        for (int q = 0; q < a.num_freqs; ++q) {
-                            put(dcode + (2 * q + h) * dcode + i, __sinf(fmaf(xi, f, ph)));
-                            f *= 2.0f;
+                    auto image = [&](auto dc) {
+                        constexpr int D = decltype(dc)::value;
+                        constexpr int SL = 8 * ((6 * D + 4 + 7) / 8);
+                        const float vv[6] = {xr[0], xr[1], xr[2], dr[0], dr[1], dr[2]};
+                        float val[SL];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) {
+                            const float fq = a.freq_factor * (float)(1 << q);
+#pragma unroll
+                            for (int i = 0; i < D; ++i) val[q * D + i] = __sinf(fmaf(vv[i], fq, ph));
                         }
-                    }
-                    if (!a.use_code_viewdirs && h == 1) {
-                        const int k0 = 3 + 6 * a.num_freqs;
-                        put(k0, dr[0]); put(k0 + 1, dr[1]); put(k0 + 2, dr[2]);
-                    }
-                    if (h == 0) { put(a.d_in, 1.0f); put(a.d_in + 1, 1.0f); }     // folded lin_in bias (hi, lo)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) val[6 * D + t] = h ? dr[t] : xr[t];
+                        val[6 * D + 3] = 1.0f;                       // folded lin_in bias (h=0: hi part, h=1: lo part)
+#pragma unroll
+                        for (int i = 6 * D + 4; i < SL; ++i) val[i] = 0.f;
+#pragma unroll
+                        for (int s = 0; s < SL / 8; ++s) {
+                            uint4 o;
+                            o.x = NM::pack(val[8 * s + 0], val[8 * s + 1]); o.y = NM::pack(val[8 * s + 2], val[8 * s + 3]);
+                            o.z = NM::pack(val[8 * s + 4], val[8 * s + 5]); o.w = NM::pack(val[8 * s + 6], val[8 * s + 7]);
+                            *(uint4*)(zwave + s * 1024 + lane * 16) = o;
+                        }
+                    };
+                    if (a.use_code_viewdirs) image(std::integral_constant<int, 6>{});
+                    else image(std::integral_constant<int, 3>{});
                 }
                 STAMP_ACC(1, st_t);
                 // ---- LIN_IN: x = W_in . features
@@ -823,6 +841,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     if (ws_bytes < point_mfma_workspace_bytes(mlp, vw)) return PNR_E_WORKSPACE;
     if (vw->n_views > 1 && y.nb1 == 0) return PNR_E_UNSUPPORTED;     // reduction before the first block
     if (prm->use_code_viewdirs ? (mlp->d_in != 6 + 12 * prm->num_freqs) : (mlp->d_in != 6 + 6 * prm->num_freqs)) return PNR_E_SHAPE;
+    if (prm->num_freqs != 6) return PNR_E_UNSUPPORTED;     // the LIN_IN slot layout is built for 6 frequencies (every shipped config)
 
     MfmaArgs a;
     a.vw = *vw; a.src = src; a.n_points = n_points; a.pts_per_obj = pts_per_obj;

@@ -350,4 +350,4 @@ def mlp_tensors(mlp):
 def mfma_supported(mlp, net):
     """Shapes the fused MFMA kernel is specialised for (csrc/point_mfma.hip)."""
     return (mlp.d_hidden == 512 and mlp.d_out == 4 and mlp.d_latent % 256 == 0 and mlp.d_latent > 0
-            and mlp.d_in <= 80 and 1 <= mlp.n_blocks <= 8)
+            and mlp.d_in in (42, 78) and net.code.num_freqs == 6 and 1 <= mlp.n_blocks <= 8)
