@@ -767,8 +767,24 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         }
 
         // ---- lin_out(relu(x)), sigmoid / relu (models.py.backup2:274-281)
-        snapshot();
         f32x16 o;
+#ifndef PNR_NO_ASM_RESBLOCK
+        {
+            // hand-scheduled: each tile's relu/convert sits right before the two MFMAs that consume it (resblock_asm.inc)
+            int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
+            float o0, o1, o2, o3;
+            if (DT == PNR_BF16)
+                asm volatile(PNR_LINOUT_ASM_BF16 : PNR_ASM_STATE_OPERANDS, "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off) : PNR_RESBLOCK_CLOBBERS);
+            else
+                asm volatile(PNR_LINOUT_ASM_F16 : PNR_ASM_STATE_OPERANDS, "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off) : PNR_RESBLOCK_CLOBBERS);
+            asm_resync(st_, li_, ls_, lr_, lw_);
+            const float* bo = btab + a.n_blocks * HID;
+            o[0] = o0 + bo[0]; o[1] = o1 + bo[1]; o[2] = o2 + bo[2]; o[3] = o3 + bo[3];
+        }
+#else
+        snapshot();
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[i] = 0.f;
         if (h == 0) {
@@ -776,6 +792,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             o[0] = bo[0]; o[1] = bo[1]; o[2] = bo[2]; o[3] = bo[3];
         }
         o = chunk_from_xb(o);
+#endif
         if (h == 0 && live) {                     // rows 0..3 of the output tile sit in registers 0..3 of lanes 0..31
             float4 res;
             res.x = 1.0f / (1.0f + __expf(-o[0]));

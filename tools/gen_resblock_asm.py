@@ -375,6 +375,112 @@ def gen_xstages(dt):
     return L
 
 
+def gen_linout(dt):
+    """lin_out(relu(x)): the snapshot of tile t (relu + 16-bit pack of a[16t:16t+15]) is emitted right before the two MFMAs
+    that consume it, so the conversion VALU work hides the chain's MFMAs; 2 stages, one accumulator (v40-55, rows 0..3 of
+    the output tile are valid), returned in %21-%24 (the caller adds lin_out.bias and applies sigmoid / relu).
+    Operands: %0-%15 x tiles, %16-%20 cursor in/out, %21-%24 out (=&v), %25 cfg, %26 stream, %27 ring+wave*4096 (s),
+    %28 ring+lane*16 (v), %29 DMA lane offset (v)."""
+    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
+    cvt = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[dt]
+    L = []
+    e = L.append
+
+    def loader_advance():
+        e("s_add_u32 s21, s21, 1")
+        e("s_add_u32 s24, s24, 0x4000")
+        e("s_addc_u32 s25, s25, 0")
+        e("s_cmp_lg_u32 s21, s29")
+        e("s_cbranch_scc1 2f")
+        e("s_mov_b32 s21, 0")
+        e("s_mov_b64 s[24:25], s[36:37]")
+        e("s_add_u32 s23, s23, 1")
+        e("s_cmp_lg_u32 s23, s28")
+        e("s_cselect_b32 s23, s23, 0")
+        e("s_sub_u32 s35, s28, 1")
+        e("s_cmp_eq_u32 s23, s35")
+        e("s_cselect_b32 s29, s27, s26")
+        e("2:")
+
+    def relu_pack(dst, a0, a1, tmp):
+        e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
+        e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
+        e(f"{cvt} v{dst}, v{tmp}, v{tmp + 1}")
+        e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
+        if dt == "f16":
+            e(f"v_pk_min_i16 v{dst}, v{dst}, s38")
+
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_mov_b32 s39, m0")
+    e("s_mov_b32 s20, %16")
+    e("s_mov_b32 s21, %17")
+    e("s_mov_b32 s22, %18")
+    e("s_mov_b32 s23, %19")
+    e("s_mov_b32 s29, %20")
+    e("s_and_b32 s26, %25, 0x3ff")
+    e("s_bfe_u32 s27, %25, 0xa000a")
+    e("s_bfe_u32 s28, %25, 0x80014")
+    e("s_mov_b64 s[36:37], %26")
+    e("s_lshl_b32 s35, s21, 14")
+    e("s_add_u32 s24, s36, s35")
+    e("s_addc_u32 s25, s37, 0")
+    if dt == "f16":
+        e("s_mov_b32 s38, 0x7bff7bff")
+    for k in range(3):                                       # read bases of stage 0, stage 1 and the stage after (read-ahead only)
+        e(f"s_add_u32 s35, s20, {k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"v_add_u32 v{10 + k}, s35, %28")
+    for k in range(2):                                       # DMA destinations of the two stages loaded meanwhile
+        e(f"s_add_u32 s35, s22, {k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"s_add_u32 s{40 + k}, s35, %27")
+    e("v_mov_b32 v15, %29")
+    for i in range(16):
+        e(f"v_mov_b32 v{40 + i}, 0")
+    for i in range(8):
+        e(f"ds_read_b128 {A(i)}, v10 offset:{i * 1024}")
+    for half in range(2):
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+        for f in range(16):
+            t = 8 * half + (f >> 1)
+            if f % 2 == 0:
+                for sidx in range(2):
+                    for pidx in range(4):
+                        relu_pack(128 + (t * 2 + sidx) * 4 + pidx, 16 * t + 8 * sidx + 2 * pidx, 16 * t + 8 * sidx + 2 * pidx + 1, 68 + 2 * (pidx & 1))
+            if f % 4 == 0:
+                e("s_waitcnt lgkmcnt(4)")
+            e(f"{mfma} v[40:55], {A(f & 7)}, {XB(t, f & 1)}, v[40:55]")
+            base = 10 + half if f < 8 else 11 + half
+            e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
+            if f % 4 == 1:
+                q = f >> 2
+                if q == 0:
+                    e(f"s_mov_b32 m0, s{40 + half}")
+                    e("s_nop 0")
+                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                if q == 3:
+                    loader_advance()
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 15")
+    e("s_nop 15")
+    for i in range(4):
+        e(f"v_mov_b32 %{21 + i}, v{40 + i}")
+    e("s_mov_b32 m0, s39")
+    e("s_add_u32 s20, s20, 2")
+    e("s_and_b32 %16, s20, 3")
+    e("s_mov_b32 %17, s21")
+    e("s_add_u32 s22, s22, 2")
+    e("s_and_b32 %18, s22, 3")
+    e("s_mov_b32 %19, s23")
+    e("s_mov_b32 %20, s29")
+    return L
+
+
 def gen_viewspill():
     """Park this view's residual stream: x (16 tiles) -> workspace slot, float4 index (t*4+q)*64 + lane.
     Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v)."""
@@ -460,6 +566,7 @@ def main():
         f.write("// GENERATED by tools/gen_resblock_asm.py — do not edit.  See that file for the register contract.\n")
         for dt, name, fn in (("bf16", "PNR_RESBLOCK_ASM_BF16", gen), ("f16", "PNR_RESBLOCK_ASM_F16", gen),
                              ("bf16", "PNR_XSTAGES_ASM_BF16", gen_xstages), ("f16", "PNR_XSTAGES_ASM_F16", gen_xstages),
+                             ("bf16", "PNR_LINOUT_ASM_BF16", gen_linout), ("f16", "PNR_LINOUT_ASM_F16", gen_linout),
                              (None, "PNR_VIEWSPILL_ASM", gen_viewspill), (None, "PNR_VIEWREDUCE_ASM", gen_viewreduce)):
             lines = fn(dt) if dt else fn()
             f.write(f"#define {name} \\\n")
