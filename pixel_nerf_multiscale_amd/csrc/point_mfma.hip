@@ -529,6 +529,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         return hacc;
     };
 
+    const bool small_idx = a.n_points < 0x7fffffffLL;
     const int n_groups = a.proj ? 1 : a.SZ / 16;  // latent channel groups of 256 (the LDS image holds one)
     const int z_steps = a.proj ? a.SZ : 16;       // k-steps per lin_z call (projected: the texel k-steps)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -539,7 +540,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         const int64_t g = (int64_t)tile * TILE_PTS + wv * 32 + r;
         const bool live = g < a.n_points;
         const int64_t gc = live ? g : a.n_points - 1;
-        const int obj = (int)(gc / a.pts_per_obj);
+        // 64-bit divisions are ~100 instructions each on this machine: one object / point counts below 2^31 take 32-bit paths
+        const int obj = a.vw.n_objs == 1 ? 0 : (small_idx ? (int)((uint32_t)gc / (uint32_t)a.pts_per_obj) : (int)(gc / a.pts_per_obj));
         float pu = 0.f, pv = 0.f;
         int v = 0, b = 0, view = 0;
         bool start = true;
@@ -614,10 +616,22 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 view = obj * a.NS + v;
                 const Cam cam = load_cam(a.vw, view);
                 float p[3], d[3], xr[3], dr[3];
-                fetch_point(a.src, gc, p, d);
+                if (small_idx && a.src.rays) {               // fetch_point with a 32-bit ray index
+                    const uint32_t ray = (uint32_t)gc / (uint32_t)a.src.K;
+                    const float* rp = a.src.rays + (size_t)ray * 8;
+                    const float zz = a.src.z[gc];
+                    d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
+                    p[0] = rp[0] + zz * d[0]; p[1] = rp[1] + zz * d[1]; p[2] = rp[2] + zz * d[2];
+                } else {
+                    fetch_point(a.src, gc, p, d);
+                }
                 rot3(cam.R, p, xr);
                 rot3(cam.R, d, dr);
                 project(cam, xr, pu, pv);
+#ifdef PNR_STAMPS
+                { float sink = pu + pv + xr[0] + dr[0]; asm volatile("" :: "v"(sink)); }
+                STAMP_ACC(8, st_t);
+#endif
                 // ---- positional features -> wave-private LDS image [k-step][lane][8] (16-bit) in the slot layout of
                 //      make_layout: every lane builds its own 8 entries per k-step (uniform code: lane half h takes the
                 //      phase-h sines, h=0 the raw x_rot, h=1 the rotated view dir) and stores them with one ds_write_b128.

@@ -19,7 +19,7 @@ import time
 torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(5): rend(net, rays)
 torch.cuda.synchronize(); print("ms/frame (stamped build)", (time.perf_counter()-t0)/5*1e3)
-names = ["tile total", "prologue(geom+posenc)", "lin_in+gather", "lin_z", "snapshot", "bias stage", "chunk loop", "lin_out+store", "  [vmcnt wait]", "  [dma issue]", "  [barrier]", "-"]
+names = ["tile total", "prologue(geom+posenc)", "lin_in+gather", "lin_z", "snapshot", "bias stage", "chunk loop", "lin_out+store", "  [geom loads+project]", "  [dma issue]", "  [barrier]", "-"]
 tot = buf[0]
 for i, n in enumerate(names):
     print(f"{n:24s} {buf[i]/tot*100:6.2f}%   cycles/wave/tile = {buf[i]/ (3*1024*64):10.0f}")
