@@ -628,6 +628,44 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
     }
 }
 
+// Latent gradient for ONE small map (C*T floats fit in LDS): a block owns a run of points of one (object, view), sums
+// their tap contributions in LDS ([texel][channel]: lanes = channels, conflict-free ds_add_f32) and flushes each entry
+// with a single global atomic — ~100x fewer global atomics than the per-point scatter of k_features_bwd, which on an
+// 8x8 map serialises on 64 texels.  dzx rows are view-major (row = v*P + g).
+static __global__ void __launch_bounds__(256) k_latent_grad_lds(
+    pnr_views vw, PointSrc src, int64_t P, int64_t pts_per_obj, int L, const float* __restrict__ dzx, int ldz,
+    float* __restrict__ d_lat, int pts_per_block) {
+    extern __shared__ float acc[];                         // [T][C]
+    const int C = vw.lat_c[0], W = vw.lat_w[0], H = vw.lat_h[0], T = W * H;
+    const int view = blockIdx.y, obj = view / vw.n_views, v = view % vw.n_views;
+    const int64_t g0 = (int64_t)obj * pts_per_obj + (int64_t)blockIdx.x * pts_per_block;
+    const int64_t g1 = min((int64_t)(obj + 1) * pts_per_obj, g0 + pts_per_block);
+    for (int i = threadIdx.x; i < T * C; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Cam cam = load_cam(vw, view);
+    for (int64_t g = g0 + wv; g < g1; g += 4) {            // one wave per point
+        float p[3], d[3], xr[3], u, w;
+        fetch_point(src, g, p, d);
+        rot3(cam.R, p, xr);
+        project(cam, xr, u, w);
+        Taps t = bilinear_taps(u, w, W, H);
+        const float* drow = dzx + ((size_t)v * P + g) * ldz;
+        for (int ch = lane; ch < C; ch += 64) {
+            float gz = drow[ch];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (t.w[i] != 0.f) atomicAdd(&acc[t.off[i] * C + ch], gz * t.w[i]);
+        }
+    }
+    __syncthreads();
+    float* out = d_lat + (size_t)view * C * T;             // (view, C, H, W)
+    for (int i = threadIdx.x; i < T * C; i += 256) {
+        float a = acc[i];
+        if (a != 0.f) atomicAdd(out + (size_t)(i % C) * T + i / C, a);
+    }
+}
+
 // ------------------------------------------------------------------ composite backward (nerf.py:178-182,223-249)
 // One wave per ray, samples walked from the far end so the suffix sum S_k = sum_{j>k} G_j w_j is a running
 // carry:  G_k = dL/dw_k = gw_k + g_rgb.c_k + g_depth z_k - [white] sum(g_rgb);
@@ -952,6 +990,18 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     if ((want_p || want_lat) && L > 0 && !dz_started) PNR_HIP_CHECK(hipMemsetAsync(dzx, 0, (size_t)MV * E * 4, s));
     if (want_p)
         PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s, half)));
+    // small single-level map: latent gradient through LDS-privatised sums (k_latent_grad_lds)
+    if (want_lat && L > 0 && vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024) {
+        const int ppb = 1024;
+        const size_t lds = (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4;
+        dim3 grid((unsigned)((pts_per_obj + ppb - 1) / ppb), vw->n_objs * vw->n_views);
+        if (lds > 48 * 1024)
+            PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_latent_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_latent_grad_lds, grid, dim3(256), lds, s, *vw, src, P, pts_per_obj, L, dzx, E, lg.p[0], ppb);
+        PNR_LAUNCH_CHECK();
+        lg.p[0] = nullptr;
+        want_lat = false;
+    }
     if (want_p || (want_lat && L > 0)) {
         hipLaunchKernelGGL(k_features_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, *vw, src, P, pts_per_obj, L, Din,
                            prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, E, lg, d_xyz, d_z);
