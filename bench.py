@@ -59,7 +59,7 @@ def executed_ratio(spec, net):
     d_in = 78 if spec["use_code_viewdirs"] else 42
     alg = flops_per_point(NS, L, d_in)
     T = spec["lat"][0][1] * spec["lat"][0][2]
-    projected = net.project_latent and NS * spec["SB"] == 1 and len(spec["lat"]) == 1 and T <= 128
+    projected = net.project_latent and spec["SB"] == 1 and NS <= 8 and len(spec["lat"]) == 1 and T <= 128
     Lz = ((T + 15) // 16) * 16 if projected else L
     d_pad = ((d_in + 2 + 15) // 16) * 16                      # lin_in k is padded to 16 (bias folded into 2 spare slots)
     return flops_per_point(NS, Lz, d_pad) / alg

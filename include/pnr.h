@@ -138,11 +138,12 @@ const char* pnr_error_string(int32_t code);
  * (bf16 or fp16; biases folded in).  `out` must hold pnr_packed_mlp_bytes() bytes, 16-B aligned. */
 uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
 int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
-/* Projected stream: for ONE source view with ONE small latent map (views->n_objs * n_views == 1, n_levels == 1,
- * 4 <= Hl*Wl <= 128 — the SRN / NMR single-view evaluation shape) bilinear lookup and lin_z are both linear, so
+/* Projected stream: for ONE object whose source views (1..8) have ONE small latent map each (views->n_objs == 1,
+ * n_levels == 1, 4 <= Hl*Wl <= 128 — the SRN / NMR evaluation shapes) bilinear lookup and lin_z are both linear, so
  * lin_z_b(index(uv)) = (W_z,b . Lat) . w(uv) with w the point's 4 tap weights spread over the Hl*Wl texels.  The
  * stream then carries W_z,b . Lat (512 x Hl*Wl) in place of W_z,b (512 x d_latent) and the kernel needs no latent
- * gather.  Re-pack whenever the weights OR the latent map change; pnr_packed_mlp_projected_bytes() returns 0 when
+ * gather; with several views the per-view part of the stream is laid out once per view, each copy with its own
+ * view's product.  Re-pack whenever the weights OR the latent maps change; pnr_packed_mlp_projected_bytes() returns 0 when
  * the shapes do not qualify.  Set pnr_mlp.packed_texels = Hl*Wl on the struct that carries this stream. */
 uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views);
 int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,

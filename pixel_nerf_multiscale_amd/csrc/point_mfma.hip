@@ -111,12 +111,12 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t p) {
 // stream then carries the (512 x T) products M_b = W_z,b . Lat in place of W_z,b: ceil(T/16) k-steps instead of L/16,
 // and the per-point latent gather disappears (the B operand is the tap-weight image).
 struct Layout {
-    int d_in, d_in_pad, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK;
+    int d_in, d_in_pad, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK, PV;   // PV: per-view copies of the P1 part (projected), else 1
     uint64_t btab_bytes, stream_bytes, total_bytes, proj_bytes;
 };
 static constexpr int BLOCK_STAGES = 1 + 16 * 4;
 
-__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0) {
+__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0, int proj_views = 1) {
     if (m.d_hidden != HID || m.d_out != 4 || m.d_latent <= 0 || (m.d_latent % 256) != 0 || m.d_latent > 1024) return false;
     if (m.n_blocks < 1 || m.n_blocks > PNR_MAX_BLOCKS || m.d_in < 1 || m.d_in > 78) return false;
     // LIN_IN k layout (chosen for the kernel, see the prologue): lane half h of k-step s, element j holds slot 8 s + j of
@@ -140,8 +140,12 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int pro
     y.P2 = y.nb2 * BLOCK_STAGES + 2;
     y.btab_floats = ((m.n_blocks * HID + 4 + 63) / 64) * 64;
     y.btab_bytes = (uint64_t)y.btab_floats * 4;
-    y.stream_bytes = (uint64_t)(y.P1 + y.P2) * STAGE_BYTES;
-    y.proj_bytes = proj_T > 0 ? (uint64_t)(y.nb1 > 0 ? y.nb1 : 1) * HID * y.ZK * 4 : 0;   // fp32 M_b scratch behind the stream
+    // projected: the per-view part of the stream is materialised once per source view ([P1 view 0][P1 view 1]..[P2]) with
+    // that view's M_b inside, so a tile consumes ONE linear stream of PV*P1 + P2 stages
+    y.PV = proj_T > 0 ? proj_views : 1;
+    if (y.PV < 1 || y.PV * y.P1 + y.P2 > 4095) return false;
+    y.stream_bytes = (uint64_t)(y.PV * y.P1 + y.P2) * STAGE_BYTES;
+    y.proj_bytes = proj_T > 0 ? (uint64_t)y.PV * (y.nb1 > 0 ? y.nb1 : 1) * HID * y.ZK * 4 : 0;   // fp32 M_{v,b} scratch behind the stream
     y.total_bytes = y.btab_bytes + y.stream_bytes + y.proj_bytes;
     return true;
 }
@@ -154,15 +158,17 @@ __host__ __device__ inline int perm_k(int s, int h, int j) { return 16 * s + 8 *
 // M_b[n][t] = sum_c lin_z[b].weight[n][c] * latent[c][t]  (fp32; view 0 of a single-level latent), t padded to ZK with 0
 __global__ void k_project_latent(pnr_mlp m, Layout y, const float* __restrict__ lat, int T, float* __restrict__ M) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t n_out = (int64_t)y.nb1 * HID * y.ZK;
+    int64_t n_out = (int64_t)y.PV * y.nb1 * HID * y.ZK;                 // M[view][block][n][t]
     if (i >= n_out) return;
     int t = (int)(i % y.ZK);
     int n = (int)((i / y.ZK) % HID);
-    int b = (int)(i / ((int64_t)y.ZK * HID));
+    int b = (int)((i / ((int64_t)y.ZK * HID)) % y.nb1);
+    int v = (int)(i / ((int64_t)y.ZK * HID * y.nb1));
     float acc = 0.f;
     if (t < T) {
         const float* w = m.lin_z_w[b] + (size_t)n * y.L;
-        for (int c = 0; c < y.L; ++c) acc = fmaf(w[c], lat[(size_t)c * T + t], acc);
+        const float* lv = lat + (size_t)v * y.L * T;
+        for (int c = 0; c < y.L; ++c) acc = fmaf(w[c], lv[(size_t)c * T + t], acc);
     }
     M[i] = acc;
 }
@@ -178,10 +184,13 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
         bt[i] = v;
     }
     uint16_t* st = (uint16_t*)(out + y.btab_bytes);
-    const int64_t n_elems = (int64_t)(y.P1 + y.P2) * 16 * 64 * 8;
+    const int64_t n_elems = (int64_t)(y.PV * y.P1 + y.P2) * 16 * 64 * 8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += (int64_t)gridDim.x * blockDim.x) {
         int j = (int)(e & 7), lane = (int)((e >> 3) & 63), f = (int)((e >> 9) & 15);
         int stage = (int)(e >> 13);
+        int pview = 0;                                   // which per-view copy (projected streams)
+        if (stage < y.PV * y.P1) { pview = stage / y.P1; stage -= pview * y.P1; }
+        else stage -= (y.PV - 1) * y.P1;                // phase 2 follows the last copy
         int r = lane & 31, h = lane >> 5;
         float val = 0.f;
         // ---- locate the stage
@@ -219,7 +228,7 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
             if (in_blk >= 0) {
                 if (in_blk < y.SZ) {                    // LIN_Z k-step in_blk: natural k
                     int n = 32 * f + r, k = 16 * in_blk + 8 * h + j;
-                    val = M ? M[((size_t)b * HID + n) * y.ZK + k] : m.lin_z_w[b][(size_t)n * y.L + k];
+                    val = M ? M[(((size_t)pview * y.nb1 + b) * HID + n) * y.ZK + k] : m.lin_z_w[b][(size_t)n * y.L + k];
                 } else if (in_blk == y.SZ || in_blk == y.SZ + 1) {   // bias stages: k-slot 0 = hi, 1 = lo
                     const float* bp = (in_blk == y.SZ) ? m.lin_z_b[b] : m.fc1_b[b];
                     int n = 32 * f + r;
@@ -288,6 +297,7 @@ struct MfmaArgs {
     float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
     int n_tiles, NS, combine_max;
     int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj;
+    int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
     int use_code_viewdirs, num_freqs;
     float freq_factor;
 };
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     // loader cursor: stage index in the packed stream, source-view pass it belongs to, and where that pass wraps to 0
     // (a non-last view repeats phase 1; the last view runs on into phase 2)
     int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
-    int ld_wrap = (a.NS == 1) ? a.P1 + a.P2 : a.P1;
+    int ld_wrap = (a.ldNS == 1) ? a.ldP1 + a.P2 : a.ldP1;
     const uint32_t gl_off = (uint32_t)(wv * 4096 + lane * 16);
     const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
     // piece Q (0..3) of the loader's current stage; the cursor advances after the 4th piece
@@ -365,8 +375,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             ++ld_idx;
             if (ld_idx == ld_wrap) {
                 ld_idx = 0;
-                ld_rep = (ld_rep + 1 == a.NS) ? 0 : ld_rep + 1;
-                ld_wrap = (ld_rep == a.NS - 1) ? a.P1 + a.P2 : a.P1;
+                ld_rep = (ld_rep + 1 == a.ldNS) ? 0 : ld_rep + 1;
+                ld_wrap = (ld_rep == a.ldNS - 1) ? a.ldP1 + a.P2 : a.ldP1;
             }
             dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
             dma_l = __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES);
@@ -448,7 +458,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     "+{a[80:95]}"(x[5]), "+{a[96:111]}"(x[6]), "+{a[112:127]}"(x[7]), "+{a[128:143]}"(x[8]), "+{a[144:159]}"(x[9]),      \
     "+{a[160:175]}"(x[10]), "+{a[176:191]}"(x[11]), "+{a[192:207]}"(x[12]), "+{a[208:223]}"(x[13]),                    \
     "+{a[224:239]}"(x[14]), "+{a[240:255]}"(x[15]), "+s"(st_), "+s"(li_), "+s"(ls_), "+s"(lr_), "+s"(lw_)
-    const int asm_cfg = a.P1 | ((a.P1 + a.P2) << 10) | (a.NS << 20);
+    const int asm_cfg = a.ldP1 | ((a.ldP1 + a.P2) << 12) | (a.ldNS << 24);
     const uint32_t ring_lane = lds_addr(smem + LDS_RING) + lane * 16;
     auto asm_resync = [&](int st_, int li_, int ls_, int lr_, int lw_) {     // state back from an asm block
         st_slot = st_; ld_idx = li_; ld_slot = ls_; ld_rep = lr_; ld_wrap = lw_;
@@ -856,11 +866,11 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
                    int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
     Layout y;
     const int proj = mlp->packed_texels;
-    if (!make_layout(*mlp, y, proj)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
+    if (!make_layout(*mlp, y, proj, vw->n_views)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
     if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
     if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
     if (proj) {      // the stream was packed for ONE view's latent map: it must be the map being rendered
-        if (vw->n_objs * vw->n_views != 1 || vw->n_levels != 1 || vw->lat_h[0] * vw->lat_w[0] != proj) return PNR_E_PACKED;
+        if (vw->n_objs != 1 || vw->n_levels != 1 || vw->lat_h[0] * vw->lat_w[0] != proj) return PNR_E_PACKED;
     } else {
         if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
         for (int i = 0; i < vw->n_levels; ++i) {
@@ -885,6 +895,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
     a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;
     a.btab_floats = y.btab_floats; a.d_in = mlp->d_in; a.proj = proj;
+    a.ldP1 = proj ? y.PV * y.P1 : y.P1; a.ldNS = proj ? 1 : vw->n_views;
     a.use_code_viewdirs = prm->use_code_viewdirs; a.num_freqs = prm->num_freqs; a.freq_factor = prm->freq_factor;
     int grid = num_cus();
     if (grid > MAX_GRID) grid = MAX_GRID;
@@ -925,7 +936,7 @@ extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
 
 // texel count if (mlp, views) qualifies for the projected stream, else 0
 static int projectable(const pnr_mlp* mlp, const pnr_views* vw) {
-    if (!mlp || !vw || vw->n_objs * vw->n_views != 1 || vw->n_levels != 1 || !vw->latent[0]) return 0;
+    if (!mlp || !vw || vw->n_objs != 1 || vw->n_views < 1 || vw->n_views > 8 || vw->n_levels != 1 || !vw->latent[0]) return 0;
     if (vw->lat_c[0] != mlp->d_latent || mlp->combine_layer < 1) return 0;
     int T = vw->lat_h[0] * vw->lat_w[0];
     return (T >= 4 && T <= 128) ? T : 0;
@@ -934,7 +945,7 @@ static int projectable(const pnr_mlp* mlp, const pnr_views* vw) {
 extern "C" uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views) {
     Layout y;
     int T = projectable(mlp, views);
-    if (!T || !make_layout(*mlp, y, T)) return 0;
+    if (!T || !make_layout(*mlp, y, T, views->n_views)) return 0;
     return y.total_bytes;
 }
 
@@ -943,7 +954,7 @@ extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* v
     if (!mlp || !views || !out) return PNR_E_NULL;
     int T = projectable(mlp, views);
     Layout y;
-    if (!T || !make_layout(*mlp, y, T)) return PNR_E_UNSUPPORTED;
+    if (!T || !make_layout(*mlp, y, T, views->n_views)) return PNR_E_UNSUPPORTED;
     if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
     if (out_bytes < y.total_bytes) return PNR_E_WORKSPACE;
     if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
@@ -953,7 +964,7 @@ extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* v
         if (b < y.nb1 && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
     }
     float* M = (float*)((char*)out + y.btab_bytes + y.stream_bytes);
-    int64_t n_out = (int64_t)y.nb1 * HID * y.ZK;
+    int64_t n_out = (int64_t)y.PV * y.nb1 * HID * y.ZK;
     hipLaunchKernelGGL(k_project_latent, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *mlp, y,
                        views->latent[0], T, M);
     PNR_LAUNCH_CHECK();

@@ -241,17 +241,18 @@ def test_mfma_frame_psnr(prec, floor):
 
 
 @pytest.mark.parametrize("prec,floor,floor_self", [("bf16", 50.0, 50.0), ("fp16", 65.0, 65.0)])
-@pytest.mark.parametrize("lat,image", [((256, 8, 8), (128, 128)), ((256, 5, 7), (80, 56)), ((256, 8, 16), (128, 64))])
-def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, image):
+@pytest.mark.parametrize("lat,image,NS", [((256, 8, 8), (128, 128), 1), ((256, 5, 7), (80, 56), 1), ((256, 8, 16), (128, 64), 1),
+                                          ((256, 8, 8), (64, 64), 3), ((256, 6, 6), (48, 48), 2)])
+def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, image, NS):
     """One view + one small latent map: the stream carries W_z . Lat (pnr_pack_mlp_projected) and the kernel skips the
     gather.  Same inputs through the projected stream, the general (gather + lin_z) stream and the fp32 path; also a
-    texel count that is not a multiple of 16 (5x7) and a non-square map."""
+    texel count that is not a multiple of 16 (5x7), a non-square map, and 2 / 3 source views (one stream copy per view)."""
     import ctypes as C
     from hip_util import build_net, build_renderer
     import golden_util as gu
     from pixel_nerf_multiscale_amd import _native as N
-    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=48, Kf=16, Kfd=8, lat=[lat], image=image, seed=41)
-    poses = np.stack([gu.pose_spherical(10.0, -20.0, spec["radius"])])[None]
+    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=48, Kf=16, Kfd=8, lat=[lat], image=image, seed=41, NS=NS)
+    poses = np.stack([gu.pose_spherical(10.0 + 35.0 * v, -20.0, spec["radius"]) for v in range(NS)])[None]
     W, H = image
     g = torch.Generator().manual_seed(3)
     tgt = gu.pose_spherical(60.0, -25.0, spec["radius"])

@@ -10,7 +10,7 @@ Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
   * entry: the next stage to consume (this block's fc_1-bias stage) is published, DMA of the two stages after it is
     in flight, nothing is assumed about the A-fragment registers (they are reloaded here).
   * in/out scalars: %16 st_slot, %17 ld_idx, %18 ld_slot, %19 ld_rep, %20 ld_wrap   (loader cursor, see issue_piece)
-  * inputs: %21 cfg = P1 | (P1+P2)<<10 | NS<<20, %22 stream base (s64), %23 ring LDS base + wave*4096 (s),
+  * inputs: %21 cfg = P1 | (P1+P2)<<12 | NS<<24 (loader's view of the stream), %22 stream base (s64), %23 ring LDS base + wave*4096 (s),
             %24 ring LDS base + lane*16 (v), %25 DMA lane offset wave*4096 + lane*16 (v),
             %26 LDS address of fc_0.bias[block] + 16*(lane>>5) (v), %27 bias B-fragment dword 0 (v),
             %28 lin_z B image address (v), %29 lin_z cfg2 = n_lds | bias<<8, 0 = no lin_z prefix (s)
@@ -90,9 +90,9 @@ def gen(dt):
     e("s_mov_b32 s22, %18")
     e("s_mov_b32 s23, %19")
     e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %21, 0x3ff")
-    e("s_bfe_u32 s27, %21, 0xa000a")                         # offset 10, width 10
-    e("s_bfe_u32 s28, %21, 0x80014")                         # offset 20, width 8
+    e("s_and_b32 s26, %21, 0xfff")
+    e("s_bfe_u32 s27, %21, 0xc000c")                         # offset 12, width 12
+    e("s_bfe_u32 s28, %21, 0x80018")                         # offset 24, width 8
     e("s_mov_b64 s[36:37], %22")
     e("s_lshl_b32 s35, s21, 14")
     e("s_add_u32 s24, s36, s35")
@@ -355,9 +355,9 @@ def gen_xstages(dt):
     e("s_mov_b32 s22, %18")
     e("s_mov_b32 s23, %19")
     e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %21, 0x3ff")
-    e("s_bfe_u32 s27, %21, 0xa000a")
-    e("s_bfe_u32 s28, %21, 0x80014")
+    e("s_and_b32 s26, %21, 0xfff")
+    e("s_bfe_u32 s27, %21, 0xc000c")
+    e("s_bfe_u32 s28, %21, 0x80018")
     e("s_mov_b64 s[36:37], %22")
     e("s_lshl_b32 s35, s21, 14")
     e("s_add_u32 s24, s36, s35")
@@ -418,9 +418,9 @@ def gen_linout(dt):
     e("s_mov_b32 s22, %18")
     e("s_mov_b32 s23, %19")
     e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %25, 0x3ff")
-    e("s_bfe_u32 s27, %25, 0xa000a")
-    e("s_bfe_u32 s28, %25, 0x80014")
+    e("s_and_b32 s26, %25, 0xfff")
+    e("s_bfe_u32 s27, %25, 0xc000c")
+    e("s_bfe_u32 s28, %25, 0x80018")
     e("s_mov_b64 s[36:37], %26")
     e("s_lshl_b32 s35, s21, 14")
     e("s_add_u32 s24, s36, s35")
