@@ -58,9 +58,10 @@ def executed_ratio(spec, net):
     NS, L = spec["NS"], sum(c for c, _, _ in spec["lat"])
     d_in = 78 if spec["use_code_viewdirs"] else 42
     alg = flops_per_point(NS, L, d_in)
-    T = spec["lat"][0][1] * spec["lat"][0][2]
-    projected = net.project_latent and spec["SB"] == 1 and NS <= 8 and len(spec["lat"]) == 1 and T <= 128
-    Lz = ((T + 15) // 16) * 16 if projected else L
+    T = spec["lat"][-1][1] * spec["lat"][-1][2]                # the projected (last) level
+    projected = (net.project_latent and spec["SB"] == 1 and NS <= 8 and spec["lat"][-1][0] == 256 and (L - 256) % 256 == 0
+                 and T <= 256)
+    Lz = (L - 256) + ((T + 15) // 16) * 16 if projected else L
     d_pad = ((d_in + 2 + 15) // 16) * 16                      # lin_in k is padded to 16 (bias folded into 2 spare slots)
     return flops_per_point(NS, Lz, d_pad) / alg
 

@@ -61,8 +61,8 @@ typedef struct pnr_mlp {
     const void* packed;
     uint64_t packed_bytes;
     int32_t packed_dtype;        /* PNR_BF16 / PNR_F16 */
-    int32_t packed_texels;       /* 0: plain stream (pnr_pack_mlp).  T > 0: stream from pnr_pack_mlp_projected for a
-                                  * single latent map of T = Hl*Wl texels (lin_z pre-multiplied with the map) */
+    int32_t packed_texels;       /* 0: plain stream (pnr_pack_mlp).  T > 0: stream from pnr_pack_mlp_projected; T = Hl*Wl of
+                                  * the last latent level (lin_z pre-multiplied with that level's maps) */
 } pnr_mlp;
 
 /* What PixelNeRFNet.encode() leaves on the module (models.py.backup2:108-150) + the encoder's latent
@@ -138,8 +138,9 @@ const char* pnr_error_string(int32_t code);
  * (bf16 or fp16; biases folded in).  `out` must hold pnr_packed_mlp_bytes() bytes, 16-B aligned. */
 uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
 int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
-/* Projected stream: for ONE object whose source views (1..8) have ONE small latent map each (views->n_objs == 1,
- * n_levels == 1, 4 <= Hl*Wl <= 128 — the SRN / NMR evaluation shapes) bilinear lookup and lin_z are both linear, so
+/* Projected stream: for ONE object (views->n_objs == 1, 1..8 source views) whose LAST latent level has 256 channels on
+ * 4 <= Hl*Wl <= 256 texels (single-scale SRN / NMR maps; the coarsest level of the multi-scale encoder — the levels
+ * before it, whole 256-channel groups, are still gathered) bilinear lookup and lin_z are both linear, so
  * lin_z_b(index(uv)) = (W_z,b . Lat) . w(uv) with w the point's 4 tap weights spread over the Hl*Wl texels.  The
  * stream then carries W_z,b . Lat (512 x Hl*Wl) in place of W_z,b (512 x d_latent) and the kernel needs no latent
  * gather; with several views the per-view part of the stream is laid out once per view, each copy with its own

@@ -111,12 +111,12 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t p) {
 // stream then carries the (512 x T) products M_b = W_z,b . Lat in place of W_z,b: ceil(T/16) k-steps instead of L/16,
 // and the per-point latent gather disappears (the B operand is the tap-weight image).
 struct Layout {
-    int d_in, d_in_pad, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK, PV;   // PV: per-view copies of the P1 part (projected), else 1
+    int d_in, d_in_pad, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK, PV, Gg;   // PV: per-view copies of the P1 part (projected), else 1; Gg: 256-channel groups still gathered
     uint64_t btab_bytes, stream_bytes, total_bytes, proj_bytes;
 };
 static constexpr int BLOCK_STAGES = 1 + 16 * 4;
 
-__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0, int proj_views = 1) {
+__host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int proj_T = 0, int proj_views = 1, int proj_gathered = 0) {
     if (m.d_hidden != HID || m.d_out != 4 || m.d_latent <= 0 || (m.d_latent % 256) != 0 || m.d_latent > 1024) return false;
     if (m.n_blocks < 1 || m.n_blocks > PNR_MAX_BLOCKS || m.d_in < 1 || m.d_in > 78) return false;
     // LIN_IN k layout (chosen for the kernel, see the prologue): lane half h of k-step s, element j holds slot 8 s + j of
@@ -128,10 +128,14 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int pro
     y.S_in = (6 * y.D + 4 + 7) / 8;                  // 3 or 5 k-steps
     y.d_in_pad = 16 * y.S_in;
     y.L = m.d_latent;
-    if (proj_T < 0 || proj_T > 128) return false;
+    // projected: the LAST latent level (256 channels, T <= 256 texels) is folded into lin_z; the Gg 256-channel groups of
+    // the levels before it are still gathered.  lin_z k-steps: 16 per gathered group, then ceil(T/16) texel steps.
+    if (proj_T < 0 || proj_T > 256 || proj_gathered < 0) return false;
+    if (proj_T > 0 && m.d_latent != 256 * (proj_gathered + 1)) return false;
     y.proj_T = proj_T;
-    y.SZ = proj_T > 0 ? (proj_T + 15) / 16 : m.d_latent / 16;
-    y.ZK = y.SZ * 16;                               // k extent of a lin_z stage group
+    y.Gg = proj_T > 0 ? proj_gathered : 0;
+    y.ZK = proj_T > 0 ? ((proj_T + 15) / 16) * 16 : 0;  // texel extent (padded) of the projected part
+    y.SZ = proj_T > 0 ? 16 * y.Gg + y.ZK / 16 : m.d_latent / 16;
     y.n_blocks = m.n_blocks;
     y.nb1 = m.combine_layer < m.n_blocks ? m.combine_layer : m.n_blocks;
     if (y.nb1 < 0) y.nb1 = 0;
@@ -166,9 +170,10 @@ __global__ void k_project_latent(pnr_mlp m, Layout y, const float* __restrict__ 
     int v = (int)(i / ((int64_t)y.ZK * HID * y.nb1));
     float acc = 0.f;
     if (t < T) {
-        const float* w = m.lin_z_w[b] + (size_t)n * y.L;
-        const float* lv = lat + (size_t)v * y.L * T;
-        for (int c = 0; c < y.L; ++c) acc = fmaf(w[c], lv[(size_t)c * T + t], acc);
+        const int c0 = 256 * y.Gg, Cl = y.L - c0;            // channels of the projected (last) level
+        const float* w = m.lin_z_w[b] + (size_t)n * y.L + c0;
+        const float* lv = lat + (size_t)v * Cl * T;
+        for (int c = 0; c < Cl; ++c) acc = fmaf(w[c], lv[(size_t)c * T + t], acc);
     }
     M[i] = acc;
 }
@@ -228,7 +233,8 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
             if (in_blk >= 0) {
                 if (in_blk < y.SZ) {                    // LIN_Z k-step in_blk: natural k
                     int n = 32 * f + r, k = 16 * in_blk + 8 * h + j;
-                    val = M ? M[(((size_t)pview * y.nb1 + b) * HID + n) * y.ZK + k] : m.lin_z_w[b][(size_t)n * y.L + k];
+                    val = (M && in_blk >= 16 * y.Gg) ? M[(((size_t)pview * y.nb1 + b) * HID + n) * y.ZK + (k - 256 * y.Gg)]
+                                                     : m.lin_z_w[b][(size_t)n * y.L + k];
                 } else if (in_blk == y.SZ || in_blk == y.SZ + 1) {   // bias stages: k-slot 0 = hi, 1 = lo
                     const float* bp = (in_blk == y.SZ) ? m.lin_z_b[b] : m.fc1_b[b];
                     int n = 32 * f + r;
@@ -296,7 +302,7 @@ struct MfmaArgs {
     float* out;
     float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
     int n_tiles, NS, combine_max;
-    int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj;
+    int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj, Gg;
     int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
     int use_code_viewdirs, num_freqs;
     float freq_factor;
@@ -540,8 +546,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
 
     const bool small_idx = a.n_points < 0x7fffffffLL;
-    const int n_groups = a.proj ? 1 : a.SZ / 16;  // latent channel groups of 256 (the LDS image holds one)
-    const int z_steps = a.proj ? a.SZ : 16;       // k-steps per lin_z call (projected: the texel k-steps)
+    const int n_gather = a.proj ? a.Gg : a.SZ / 16;       // 256-channel groups gathered per block (the LDS image holds one)
+    const int p_steps = a.proj ? a.SZ - 16 * a.Gg : 0;    // texel k-steps of the projected last level
+    // the last lin_z call of a block (a gathered group, or the projected part) runs as the prefix of the resblock asm
+    const int n_groups = a.proj ? n_gather : n_gather - 1;  // gathered groups that go through separate x_stages calls
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         STAMP(st_t);
 #ifdef PNR_STAMPS
@@ -607,9 +615,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         // ---- projected mode: the B operand of lin_z is the point's tap-weight vector over the T texels,
         //      image [k-step][lane half][col][8]: texel t sits at k-step t/16, half (t/8)&1, element t&7
         auto tap_image = [&]() {
-            const Taps tp = bilinear_taps(pu, pv, a.vw.lat_w[0], a.vw.lat_h[0]);
+            const int ll = a.vw.n_levels - 1;
+            const Taps tp = bilinear_taps(pu, pv, a.vw.lat_w[ll], a.vw.lat_h[ll]);
             const uint4 z4 = {0u, 0u, 0u, 0u};
-            for (int s = 0; s < a.SZ; ++s) *(uint4*)(zwave + s * 1024 + lane * 16) = z4;
+            for (int s = 0; s < p_steps; ++s) *(uint4*)(zwave + s * 1024 + lane * 16) = z4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int t = tp.off[2 * h + i];
@@ -688,21 +697,22 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #else
                 x_stages(a.S_in, 0);
 #endif
-                if (a.proj) tap_image();
-                else if (n_groups == 1) gather(0);
+                if (a.proj && n_gather == 0) tap_image();          // fully projected: the image serves all blocks of this view
+                else if (!a.proj && n_gather == 1) gather(0);
                 STAMP_ACC(2, st_t);
             }
             // ---- x += lin_z[b](z)  (blocks before the view reduction only)
-            // one channel group / projected texels: the lin_z stages run as the prefix of the resblock's asm block below
-            if (b < a.nb1 && n_groups > 1) {
-                for (int grp = 0; grp < n_groups; ++grp) {
+            if (b < a.nb1) {
+                for (int grp = 0; grp < n_groups; ++grp) {         // all but the block's last lin_z part
                     gather(grp);
 #ifdef PNR_X_NO_ASM_LINZ
-                    x_stages(z_steps, grp == n_groups - 1 ? 1 : 0, false);
+                    x_stages(16, 0, false);
 #else
-                    x_stages(z_steps, grp == n_groups - 1 ? 1 : 0);   // last group: + lin_z.bias
+                    x_stages(16, 0);
 #endif
                 }
+                if (a.proj && n_gather > 0) tap_image();           // partial projection: the buffer was just used by the gather
+                else if (!a.proj && n_gather > 1) gather(n_gather - 1);
             }
             STAMP_ACC(3, st_t);
             // ---- resblock: x += fc_1(relu(fc_0(relu(x)))) + biases  (resnetfc.py:53-62)
@@ -712,7 +722,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 int st_ = st_slot, li_ = ld_idx, ls_ = ld_slot, lr_ = ld_rep, lw_ = ld_wrap;
                 const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + h * 16;
                 const uint32_t zaddr = lds_addr(zwave) + lane * 16;
-                const int cfg2z = (b < a.nb1 && n_groups == 1) ? (z_steps | (1 << 8)) : 0;      // lin_z prefix: k-steps + bias stage
+                const int cfg2z = (b < a.nb1) ? ((a.proj ? p_steps : 16) | (1 << 8)) : 0;       // lin_z prefix: last part + bias stage
                 if (DT == PNR_BF16)
                     asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
                                  : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(b_bias.x),
@@ -866,14 +876,18 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
                    int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
     Layout y;
     const int proj = mlp->packed_texels;
-    if (!make_layout(*mlp, y, proj, vw->n_views)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
+    const int last = vw->n_levels - 1;
+    const int gathered = proj ? (mlp->d_latent - vw->lat_c[last]) / 256 : 0;
+    if (proj && (vw->lat_c[last] != 256 || (mlp->d_latent - 256) % 256 != 0)) return PNR_E_PACKED;
+    if (!make_layout(*mlp, y, proj, vw->n_views, gathered)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
     if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
     if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
     if (proj) {      // the stream was packed for ONE view's latent map: it must be the map being rendered
-        if (vw->n_objs != 1 || vw->n_levels != 1 || vw->lat_h[0] * vw->lat_w[0] != proj) return PNR_E_PACKED;
-    } else {
+        if (vw->n_objs != 1 || vw->lat_h[last] * vw->lat_w[last] != proj) return PNR_E_PACKED;
+    }
+    if (!proj || gathered > 0) {
         if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
-        for (int i = 0; i < vw->n_levels; ++i) {
+        for (int i = 0; i < (proj ? last : vw->n_levels); ++i) {
             if (!vw->latent_packed[i]) return PNR_E_PACKED;
             if (((uintptr_t)vw->latent_packed[i] & 15) != 0) return PNR_E_ALIGN;
             if (vw->lat_c[i] % 16 != 0) return PNR_E_UNSUPPORTED;
@@ -894,7 +908,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
     a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
     a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;
-    a.btab_floats = y.btab_floats; a.d_in = mlp->d_in; a.proj = proj;
+    a.btab_floats = y.btab_floats; a.d_in = mlp->d_in; a.proj = proj; a.Gg = y.Gg;
     a.ldP1 = proj ? y.PV * y.P1 : y.P1; a.ldNS = proj ? 1 : vw->n_views;
     a.use_code_viewdirs = prm->use_code_viewdirs; a.num_freqs = prm->num_freqs; a.freq_factor = prm->freq_factor;
     int grid = num_cus();
@@ -934,27 +948,37 @@ extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
     return y.total_bytes;
 }
 
-// texel count if (mlp, views) qualifies for the projected stream, else 0
-static int projectable(const pnr_mlp* mlp, const pnr_views* vw) {
-    if (!mlp || !vw || vw->n_objs != 1 || vw->n_views < 1 || vw->n_views > 8 || vw->n_levels != 1 || !vw->latent[0]) return 0;
-    if (vw->lat_c[0] != mlp->d_latent || mlp->combine_layer < 1) return 0;
-    int T = vw->lat_h[0] * vw->lat_w[0];
-    return (T >= 4 && T <= 128) ? T : 0;
+// texel count of the last level if (mlp, views) qualifies for the projected stream, else 0; *gathered = 256-channel
+// groups of the levels before it
+static int projectable(const pnr_mlp* mlp, const pnr_views* vw, int* gathered) {
+    if (!mlp || !vw || vw->n_objs != 1 || vw->n_views < 1 || vw->n_views > 8 || vw->n_levels < 1 || vw->n_levels > PNR_MAX_LEVELS)
+        return 0;
+    const int last = vw->n_levels - 1;
+    if (!vw->latent[last] || vw->lat_c[last] != 256 || mlp->combine_layer < 1) return 0;
+    int L = 0;
+    for (int i = 0; i < vw->n_levels; ++i) L += vw->lat_c[i];
+    if (L != mlp->d_latent || (L - 256) % 256 != 0) return 0;
+    *gathered = (L - 256) / 256;
+    int T = vw->lat_h[last] * vw->lat_w[last];
+    // fully projected maps pay T/16 k-steps instead of 16 + the gather: worth it up to 256 texels
+    return (T >= 4 && T <= 256) ? T : 0;
 }
 
 extern "C" uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views) {
     Layout y;
-    int T = projectable(mlp, views);
-    if (!T || !make_layout(*mlp, y, T, views->n_views)) return 0;
+    int gathered = 0;
+    int T = projectable(mlp, views, &gathered);
+    if (!T || !make_layout(*mlp, y, T, views->n_views, gathered)) return 0;
     return y.total_bytes;
 }
 
 extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,
                                           uint64_t out_bytes, void* stream) {
     if (!mlp || !views || !out) return PNR_E_NULL;
-    int T = projectable(mlp, views);
+    int gathered = 0;
+    int T = projectable(mlp, views, &gathered);
     Layout y;
-    if (!T || !make_layout(*mlp, y, T, views->n_views)) return PNR_E_UNSUPPORTED;
+    if (!T || !make_layout(*mlp, y, T, views->n_views, gathered)) return PNR_E_UNSUPPORTED;
     if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
     if (out_bytes < y.total_bytes) return PNR_E_WORKSPACE;
     if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
@@ -966,7 +990,7 @@ extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* v
     float* M = (float*)((char*)out + y.btab_bytes + y.stream_bytes);
     int64_t n_out = (int64_t)y.PV * y.nb1 * HID * y.ZK;
     hipLaunchKernelGGL(k_project_latent, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *mlp, y,
-                       views->latent[0], T, M);
+                       views->latent[views->n_levels - 1], T, M);
     PNR_LAUNCH_CHECK();
     if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);
     else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);

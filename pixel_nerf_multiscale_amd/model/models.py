@@ -152,9 +152,9 @@ class PixelNeRFNet(torch.nn.Module):
 
     def mlp_struct(self, mlp, precision, views=None):
         """pnr_mlp over the module's parameter storage (+ the packed MFMA stream, cached until a
-        parameter changes).  With `views` (a pnr_views of ONE view with one small latent map) the stream is the
-        projected one (lin_z pre-multiplied with the map, see pnr_pack_mlp_projected) and is also keyed by the
-        latent.  Returns (struct, keepalive)."""
+        parameter changes).  With `views` (one object; last latent level 256 channels on <= 256 texels) the stream is the
+        projected one (lin_z pre-multiplied with that level's maps, see pnr_pack_mlp_projected) and is also keyed by
+        the latent.  Returns (struct, keepalive)."""
         m = N.pnr_mlp()
         m.d_in, m.d_latent, m.d_hidden, m.d_out = mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out
         m.n_blocks, m.combine_layer, m.combine_type = mlp.n_blocks, mlp.combine_layer, N.COMBINE[mlp.combine_type]
@@ -178,7 +178,7 @@ class PixelNeRFNet(torch.nn.Module):
             if views is not None and self.project_latent:
                 proj_bytes = N.lib.pnr_packed_mlp_projected_bytes(C.byref(m), C.byref(views))
                 if proj_bytes:
-                    mp = self.encoder.level_maps()[0]
+                    mp = self.encoder.level_maps()[-1]          # the projected (last) level
                     lat_key = (mp.data_ptr(), mp._version, tuple(mp.shape))
             key = ("mlp", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()), lat_key)
             packed = self._pack_cache.get(key)
@@ -196,7 +196,7 @@ class PixelNeRFNet(torch.nn.Module):
                                                N.current_stream(packed.device)), "pnr_pack_mlp")
                 self._pack_cache[key] = packed
             m.packed, m.packed_bytes, m.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
-            m.packed_texels = int(views.lat_h[0] * views.lat_w[0]) if proj_bytes else 0
+            m.packed_texels = int(views.lat_h[views.n_levels - 1] * views.lat_w[views.n_levels - 1]) if proj_bytes else 0
             keep.append(packed)
         return m, keep
 

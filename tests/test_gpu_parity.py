@@ -242,7 +242,8 @@ def test_mfma_frame_psnr(prec, floor):
 
 @pytest.mark.parametrize("prec,floor,floor_self", [("bf16", 50.0, 50.0), ("fp16", 65.0, 65.0)])
 @pytest.mark.parametrize("lat,image,NS", [((256, 8, 8), (128, 128), 1), ((256, 5, 7), (80, 56), 1), ((256, 8, 16), (128, 64), 1),
-                                          ((256, 8, 8), (64, 64), 3), ((256, 6, 6), (48, 48), 2)])
+                                          ((256, 8, 8), (64, 64), 3), ((256, 6, 6), (48, 48), 2), ((256, 16, 16), (128, 128), 1),
+                                          ("multiscale", (64, 64), 2)])
 def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, image, NS):
     """One view + one small latent map: the stream carries W_z . Lat (pnr_pack_mlp_projected) and the kernel skips the
     gather.  Same inputs through the projected stream, the general (gather + lin_z) stream and the fp32 path; also a
@@ -251,7 +252,13 @@ def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, ima
     from hip_util import build_net, build_renderer
     import golden_util as gu
     from pixel_nerf_multiscale_amd import _native as N
-    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=48, Kf=16, Kfd=8, lat=[lat], image=image, seed=41, NS=NS)
+    cv = False
+    if lat == "multiscale":        # 4-level encoder output: levels 0-2 (256 channels) gathered, the 16x16 level projected
+        lats, cv = [(64, 32, 32), (64, 32, 32), (128, 16, 16), (256, 8, 8)], True
+        lat = lats[-1]
+    else:
+        lats = [lat]
+    spec = dict(gu.CASES["full_ns1"]); spec.update(Kc=48, Kf=16, Kfd=8, lat=lats, image=image, seed=41, NS=NS, use_code_viewdirs=cv)
     poses = np.stack([gu.pose_spherical(10.0 + 35.0 * v, -20.0, spec["radius"]) for v in range(NS)])[None]
     W, H = image
     g = torch.Generator().manual_seed(3)
