@@ -498,7 +498,7 @@ def gen_viewspill():
 
 
 def gen_viewreduce():
-    """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max), one pass per parked view, the next tile's 4 loads
+    """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max), one pass per parked view, nine tiles' loads
     in flight while a tile is combined.  Operands: %0-%15 x (pinned), %16 slot_0 base (s64), %17 NS-1 (s),
     %18 combine_max (s), %19 lane*16 (v), %20 1/NS (v)."""
     L = []
@@ -511,15 +511,17 @@ def gen_viewreduce():
         e("s_addc_u32 s25, s25, 0")
 
     def combine_pass(op):
-        bufs = (40, 96)
-        loads(bufs[0])
+        # The parked streams sit in L2 / Infinity Cache: nine tiles (36 x 1 KiB loads per wave) are kept in flight ahead of
+        # the tile being combined.
+        NB, D = 10, 9
+        buf = lambda t: 96 + 16 * (t % NB)
+        for t in range(D):
+            loads(buf(t))
         for t in range(16):
-            if t < 15:
-                loads(bufs[(t + 1) & 1])
-                e("s_waitcnt vmcnt(4)")
-            else:
-                e("s_waitcnt vmcnt(0)")
-            b = bufs[t & 1]
+            if t + D < 16:
+                loads(buf(t + D))
+            e(f"s_waitcnt vmcnt({4 * min(D, 15 - t)})")
+            b = buf(t)
             for i in range(16):
                 tmp = 68 + (i & 3)
                 e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
