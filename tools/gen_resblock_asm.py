@@ -494,6 +494,9 @@ def gen_viewspill():
             e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
         e("s_add_u32 s24, s24, 0x1000")
         e("s_addc_u32 s25, s25, 0")
+    # The stores source their data straight from the accumulator tiles: have them retired before anything may overwrite
+    # a tile (measured: without this wait a build whose compiler-side code happened not to wait here read back wrong tiles).
+    e("s_waitcnt vmcnt(0)")
     return L
 
 
