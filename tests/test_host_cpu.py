@@ -30,14 +30,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from pixel_nerf_multiscale_amd import _native as N
-    src = '#include <stdio.h>\n#include "pnr.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(pnr_mlp), sizeof(pnr_views), sizeof(pnr_params), sizeof(pnr_noise), sizeof(pnr_outputs));return 0;}\n'
+    src = '#include <stdio.h>\n#include "pnr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(pnr_mlp), sizeof(pnr_views), sizeof(pnr_params), sizeof(pnr_noise), sizeof(pnr_outputs), sizeof(pnr_mlp_grads));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(s) for s in (N.pnr_mlp, N.pnr_views, N.pnr_params, N.pnr_noise, N.pnr_outputs)]
+    assert sizes == [ctypes.sizeof(s) for s in (N.pnr_mlp, N.pnr_views, N.pnr_params, N.pnr_noise, N.pnr_outputs, N.pnr_mlp_grads)]
 
 
 def test_null_and_shape_errors_without_gpu():
@@ -124,3 +124,50 @@ def test_container_modules_do_not_evaluate_in_pytorch():
     ms = SpatialEncoder(pretrained=False, use_multi_scale=True, use_first_pool=False)
     lats = ms(torch.zeros(2, 3, 64, 64))
     assert [tuple(l.shape[1:]) for l in lats] == [(64, 32, 32), (64, 32, 32), (128, 16, 16), (256, 8, 8)]
+
+
+def test_training_and_projection_switches_host_logic():
+    """Routing and descriptor logic that needs no GPU: which calls take the differentiable path, the parameter order the
+    training Functions exchange with the C ABI, argument errors of the training / projected-pack entry points."""
+    import hip_util as hu
+    from pixel_nerf_multiscale_amd import PixelNeRFNet, _native as N
+    from pixel_nerf_multiscale_amd.model.models import mlp_tensors
+    from pixel_nerf_multiscale_amd.render import autograd as ag
+    spec = gu.CASES["tiny_ns1"]
+    net = PixelNeRFNet(hu.model_conf(spec))
+    assert net.project_latent and net.train_precision == "fp32" and net.differentiable is None
+    x = torch.zeros(1, 4, 3)
+    net.eval()
+    assert not net.wants_grad(x)                       # eval(): fused kernels
+    net.train()
+    net.encoder.latent = torch.zeros(1, 512, 2, 2)
+    net.encoder._level_maps = [net.encoder.latent]
+    assert net.wants_grad(x)                           # training mode + parameters requiring grad
+    with torch.no_grad():
+        assert not net.wants_grad(x)
+    net.differentiable = False
+    assert not net.wants_grad(x)
+    net.differentiable = None
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert not net.wants_grad(x) and net.wants_grad(x.clone().requires_grad_(True))
+    # parameter order <-> pnr_mlp / pnr_mlp_grads slots
+    mlp = net.mlp_coarse
+    ts = mlp_tensors(mlp)
+    assert ts[0] is mlp.lin_in.weight and ts[3] is mlp.lin_out.bias and ts[4] is mlp.blocks[0].fc_0.weight
+    assert ts[-1] is mlp.lin_z[-1].bias and len(ts) == 4 + 4 * mlp.n_blocks + 2 * len(mlp.lin_z)
+    hdr = dict(n_blocks=mlp.n_blocks, n_lin_z=len(mlp.lin_z))
+    marks = [object() for _ in ts]
+
+    class P:     # stand-in with a data_ptr, so the slot mapping can be checked without device memory
+        def __init__(self, i): self.i = i
+        def data_ptr(self): return 1000 + self.i
+    g = ag._grads_struct_from(hdr, [P(i) for i in range(len(ts))])
+    assert g.lin_in_w == 1000 and g.lin_out_b == 1003 and g.fc0_w[0] == 1004 and g.fc1_b[0] == 1007
+    assert g.lin_z_b[len(mlp.lin_z) - 1] == 1000 + len(ts) - 1
+    # argument validation before any HIP call
+    assert N.lib.pnr_train_tape_bytes(None, None, 10) == 0
+    assert N.lib.pnr_composite_bwd(None, None, None, 4, 8, 0, None, None, None, None, None, None) == -1
+    assert N.lib.pnr_sample_fine_bwd(None, None, 4, 8, 4, 2, 0.01, None, 0, 0, None, None, None, None) == -1
+    assert N.lib.pnr_packed_mlp_projected_bytes(None, None) == 0
+    assert N.lib.pnr_pack_mlp_projected(None, None, N.PNR_BF16, None, 0, None) == -1
