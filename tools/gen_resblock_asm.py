@@ -23,6 +23,9 @@ import os
 import sys
 
 
+DIAG = os.environ.get("PNR_ASM_DIAG", "")      # timing experiments only: 'nobarrier', 'nodma', 'nowait' (results are garbage)
+
+
 def A(i):
     return f"v[{96 + 4 * i}:{99 + 4 * i}]"
 
@@ -566,7 +569,7 @@ def gen_viewreduce():
 
 
 def main():
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixel_nerf_multiscale_amd", "csrc", "resblock_asm.inc")
+    out = os.environ.get("PNR_ASM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixel_nerf_multiscale_amd", "csrc", "resblock_asm.inc")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_resblock_asm.py — do not edit.  See that file for the register contract.\n")
         for dt, name, fn in (("bf16", "PNR_RESBLOCK_ASM_BF16", gen), ("f16", "PNR_RESBLOCK_ASM_F16", gen),
@@ -574,6 +577,13 @@ def main():
                              ("bf16", "PNR_LINOUT_ASM_BF16", gen_linout), ("f16", "PNR_LINOUT_ASM_F16", gen_linout),
                              (None, "PNR_VIEWSPILL_ASM", gen_viewspill), (None, "PNR_VIEWREDUCE_ASM", gen_viewreduce)):
             lines = fn(dt) if dt else fn()
+            if "nobarrier" in DIAG:
+                lines = [l for l in lines if l != "s_barrier"]
+            if "nowait" in DIAG:
+                lines = [("s_nop 0" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
+            if "nodma" in DIAG:
+                lines = [l for l in lines if not l.startswith("global_load_lds")]
+                lines = [("s_nop 0" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
             f.write(f"#define {name} \\\n")
             for l in lines:
                 f.write(f'    "{l}\\n\\t" \\\n')
