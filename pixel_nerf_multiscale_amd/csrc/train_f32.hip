@@ -992,7 +992,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s, half)));
     // small single-level map: latent gradient through LDS-privatised sums (k_latent_grad_lds)
     if (want_lat && L > 0 && vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024) {
-        const int ppb = 1024;
+        const int ppb = 256;          // 128 blocks for a 4 x 8192-point step: parallel enough, 16K flush atomics per block
         const size_t lds = (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4;
         dim3 grid((unsigned)((pts_per_obj + ppb - 1) / ppb), vw->n_objs * vw->n_views);
         if (lds > 48 * 1024)
