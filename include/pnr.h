@@ -37,7 +37,9 @@ enum {
     PNR_E_PACKED = -6            /* packed weights / latents missing or of the wrong kind */
 };
 
-enum { PNR_F32 = 0, PNR_BF16 = 1, PNR_F16 = 2 };      /* arithmetic type of the fc layers */
+enum { PNR_F32 = 0, PNR_BF16 = 1, PNR_F16 = 2,          /* arithmetic type of the fc layers */
+       PNR_BF16X3 = 3 };                                 /* training entry points only: bf16 MFMA with every operand split
+                                                          * hi + lo, 3 products per term — fp32-class results */
 enum { PNR_COMBINE_AVERAGE = 0, PNR_COMBINE_MAX = 1 }; /* util.combine_interleaved (util.py:466-476) */
 
 /* ResnetFC parameters (resnetfc.py:128-158), PyTorch nn.Linear layout: weight (out,in), y = x W^T + b.

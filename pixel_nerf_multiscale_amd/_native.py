@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(HERE, "lib", "libpnr_hip.so
 PNR_MAX_LEVELS = 5
 PNR_MAX_BLOCKS = 8
 PNR_F32, PNR_BF16, PNR_F16 = 0, 1, 2
-PRECISIONS = {"fp32": PNR_F32, "f32": PNR_F32, "bf16": PNR_BF16, "fp16": PNR_F16, "f16": PNR_F16}
+PNR_BF16X3 = 3     # training entry points only
+PRECISIONS = {"fp32": PNR_F32, "f32": PNR_F32, "bf16": PNR_BF16, "fp16": PNR_F16, "f16": PNR_F16, "bf16x3": PNR_BF16X3}
 COMBINE = {"average": 0, "max": 1}
 
 _fp = C.c_void_p  # device pointers travel as integers

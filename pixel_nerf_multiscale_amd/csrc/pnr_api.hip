@@ -66,7 +66,8 @@ static int32_t check_model(const pnr_params* prm, const pnr_mlp* mlp, const pnr_
         if (b < n_lin_z && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
     }
     if (vw->n_views > 1 && mlp->combine_layer >= mlp->n_blocks) return PNR_E_UNSUPPORTED;
-    if (prm->precision != PNR_F32 && prm->precision != PNR_BF16 && prm->precision != PNR_F16) return PNR_E_UNSUPPORTED;
+    if (prm->precision != PNR_F32 && prm->precision != PNR_BF16 && prm->precision != PNR_F16 && prm->precision != PNR_BF16X3)
+        return PNR_E_UNSUPPORTED;
     return PNR_OK;
 }
 

@@ -357,8 +357,13 @@ __device__ __forceinline__ void mh_fetch(const float* __restrict__ S, int ld, in
     }
 }
 
+// residual of a bf16 pair: (f0 - bf16(f0), f1 - bf16(f1)) packed as bf16 — the "lo" part of the bf16x3 split
+__device__ __forceinline__ uint32_t pk_bf16_lo(float f0, float f1, uint32_t hi) {
+    return pk_bf16(f0 - __builtin_bit_cast(float, hi << 16), f1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
 template <bool RC, bool RELU, bool ZERO_TAIL>
-__device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int r0, int r1) {
+__device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int r0, int r1, uint16_t (*TL)[40] = nullptr) {
     const int t = threadIdx.x;
     // the loads above are unconditional and complete HERE (not earlier: hipcc would otherwise sink them into the
     // tail predicate and wait on each one)
@@ -379,6 +384,12 @@ __device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int 
         uint4 hi = {pk_bf16(f[8], f[9]), pk_bf16(f[10], f[11]), pk_bf16(f[12], f[13]), pk_bf16(f[14], f[15])};
         *(uint4*)&T[t >> 1][16 * (t & 1)] = lo;
         *(uint4*)&T[t >> 1][16 * (t & 1) + 8] = hi;
+        if (TL) {       // residual image (bf16x3)
+            uint4 l0 = {pk_bf16_lo(f[0], f[1], lo.x), pk_bf16_lo(f[2], f[3], lo.y), pk_bf16_lo(f[4], f[5], lo.z), pk_bf16_lo(f[6], f[7], lo.w)};
+            uint4 l1 = {pk_bf16_lo(f[8], f[9], hi.x), pk_bf16_lo(f[10], f[11], hi.y), pk_bf16_lo(f[12], f[13], hi.z), pk_bf16_lo(f[14], f[15], hi.w)};
+            *(uint4*)&TL[t >> 1][16 * (t & 1)] = l0;
+            *(uint4*)&TL[t >> 1][16 * (t & 1) + 8] = l1;
+        }
     } else {
         if (ZERO_TAIL) {
 #pragma unroll
@@ -390,6 +401,10 @@ __device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int 
         for (int e = 0; e < 4; ++e) {        // element (r = 4*(t&7)+i, x = 4*(t>>3)+e) is f[4 i + e]
             uint2 w = {pk_bf16(f[e], f[4 + e]), pk_bf16(f[8 + e], f[12 + e])};
             *(uint2*)&T[4 * (t >> 3) + e][4 * (t & 7)] = w;
+            if (TL) {
+                uint2 wl = {pk_bf16_lo(f[e], f[4 + e], w.x), pk_bf16_lo(f[8 + e], f[12 + e], w.y)};
+                *(uint2*)&TL[4 * (t >> 3) + e][4 * (t & 7)] = wl;
+            }
         }
     }
 }
@@ -455,6 +470,93 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
         }
         __syncthreads();
         buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lc;
+            if (n >= N) continue;
+            const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bn;
+                if (SPLIT) {
+                    atomicAdd(C + (size_t)m * ldc + n, v);
+                } else {
+                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
+                    if (R) v += R[(size_t)m * ldr + n];
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+        }
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+}
+
+// bf16x3: fp32-class products on the bf16 MFMA.  Every operand is split x = hi + lo (two bf16 images in LDS) and a
+// product is hi*hi + hi*lo + lo*hi (the lo*lo term is below 2^-16 relative): 3 MFMAs at 16x the fp32-MFMA rate, error
+// ~1e-5 instead of bf16's 4e-3.  Same contract and requirements as k_mgemm_bf16; single LDS buffer per image (40 KB),
+// the next tile's global loads fly during the MFMAs.
+template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
+static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
+    int M, int N, int Rn, int r_per_split) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];      // [hi, lo]
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float4 va[4], vb[4];
+    float rs = 0.f;
+    mh_fetch<A_RC>(A, lda, m0, M, rb, re, va);
+    mh_fetch<B_RC>(B, ldb, n0, N, rb, re, vb);
+    for (int r0 = rb; r0 < re; r0 += 32) {
+        mh_stage<A_RC, RELU_A, SPLIT>(As[0], va, r0, re, As[1]);
+        mh_stage<B_RC, RELU_B, false>(Bs[0], vb, r0, re, Bs[1]);
+        __syncthreads();
+        if (r0 + 32 < re) {
+            mh_fetch<A_RC>(A, lda, m0, M, r0 + 32, re, va);
+            mh_fetch<B_RC>(B, ldb, n0, N, r0 + 32, re, vb);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ko = 16 * s + 8 * lr;
+            bf16x8 a0h = *(const bf16x8*)&As[0][wm + lc][ko], a0l = *(const bf16x8*)&As[1][wm + lc][ko];
+            bf16x8 a1h = *(const bf16x8*)&As[0][wm + 32 + lc][ko], a1l = *(const bf16x8*)&As[1][wm + 32 + lc][ko];
+            bf16x8 b0h = *(const bf16x8*)&Bs[0][wn + lc][ko], b0l = *(const bf16x8*)&Bs[1][wn + lc][ko];
+            bf16x8 b1h = *(const bf16x8*)&Bs[0][wn + 32 + lc][ko], b1l = *(const bf16x8*)&Bs[1][wn + 32 + lc][ko];
+#define PNR_X3(ACC, AH, AL, BH, BL)                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0)
+            PNR_X3(acc[0][0], a0h, a0l, b0h, b0l);
+            PNR_X3(acc[0][1], a0h, a0l, b1h, b1l);
+            PNR_X3(acc[1][0], a1h, a1l, b0h, b0l);
+            PNR_X3(acc[1][1], a1h, a1l, b1h, b1l);
+#undef PNR_X3
+        }
+        if (rowsum && blockIdx.y == 0 && t < 128) {
+#pragma unroll
+            for (int r = 0; r < 32; r += 2) {
+                uint32_t ph = *(const uint32_t*)&As[0][t][r], pl = *(const uint32_t*)&As[1][t][r];
+                rs += (__builtin_bit_cast(float, ph << 16) + __builtin_bit_cast(float, pl << 16)) +
+                      (__builtin_bit_cast(float, ph & 0xffff0000u) + __builtin_bit_cast(float, pl & 0xffff0000u));
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -826,12 +928,16 @@ static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0
 
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
-                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, bool half = false) {
+                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, int half = 0) {
     if (M == 0) return PNR_OK;
     if (half && N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(X, ldx) && al16(W, ldw)) {
         dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
-        hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
-                           Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+        if (half == 3)
+            hipLaunchKernelGGL((k_mgemm_bf16x3<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
+                               ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+        else
+            hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
+                               ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
@@ -852,14 +958,19 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
 // dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
-                      int N, int K, hipStream_t s, bool half = false) {
+                      int N, int K, hipStream_t s, int half = 0) {
     if (!dW || M == 0) return PNR_OK;
     if (half && N >= 32 && K >= 32 && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx)) {
         const int rows = 1024;
         dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));
-        hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
-                           (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
-                           N, K, (int)M, rows);
+        if (half == 3)
+            hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
+                               N, K, (int)M, rows);
+        else
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
+                               N, K, (int)M, rows);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
@@ -900,7 +1011,8 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
-    const bool half = prm->precision == PNR_BF16;       // bf16 MFMA products on the fp32 tape (k_mgemm_bf16)
+    // GEMM products: 0 = fp32 MFMA, 1 = bf16 MFMA, 3 = bf16x3 split (fp32-class) — all on the fp32 tape
+    const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
     int64_t tot = MV * (L + Din);
     hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
                        (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
@@ -945,7 +1057,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     Tape t = carve_tape(mlp, vw, P, tape);
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
-    const bool half = prm->precision == PNR_BF16;
+    const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
     uint8_t* wp = (uint8_t*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     float* dx = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
     float* dx2 = (float*)wp;               wp += a256((uint64_t)MV * H * 4);

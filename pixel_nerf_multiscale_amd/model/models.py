@@ -75,8 +75,9 @@ class PixelNeRFNet(torch.nn.Module):
         # bf16 and ~18 dB closer to the fp32 reference) when the shape allows, else the fp32 HIP path
         self.precision = conf.get_string("precision", os.environ.get("PNR_PRECISION", "auto"))
         self.differentiable = None      # None: follow self.training; True/False: force the taped fp32 path on/off
-        # GEMM products of the differentiable path: "fp32" (fp32 MFMA, reference numerics) or "bf16" (bf16 MFMA products,
-        # fp32 accumulation / tape / gradients — like the reference's use_amp)
+        # GEMM products of the differentiable path: "fp32" (fp32 MFMA, reference numerics), "bf16x3" (bf16 MFMA on hi/lo
+        # operand splits, fp32-class results, 1.5x faster) or "bf16" (plain bf16 products — like the reference's use_amp);
+        # fp32 accumulation / tape / gradients in every mode
         self.train_precision = conf.get_string("train_precision", "fp32")
         # one source view with one small latent map: stream W_z . Lat instead of W_z and skip the gather (pnr.h,
         # pnr_pack_mlp_projected); off = always the general gather + lin_z kernel path

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--views", type=int, nargs="+", default=[1, 2])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"])
     a = ap.parse_args()
     for ns in a.views:
         spec = gu._case(seed=5, d_hidden=512, lat=[(256, 8, 8)], image=(128, 128), focal=131.25, NS=ns, SB=a.sb,
@@ -60,7 +60,7 @@ def main():
         flop_fwd = pts * 2 * (ns * 1987584 + 1050624)
         print(json.dumps({"what": "train_step", "sb": a.sb, "rays_per_obj": a.rays, "views": ns, "samples": "64+32",
                           "ms_per_step": round(ms, 2), "rays_per_s": round(n_rays / ms * 1e3),
-                          "tflops_fwd_bwd": round(3 * flop_fwd / ms / 1e9, 1), "dtype": "f32" if a.precision == "fp32" else "bf16 products, f32 accumulate"}))
+                          "tflops_fwd_bwd": round(3 * flop_fwd / ms / 1e9, 1), "dtype": {"fp32": "f32", "bf16": "bf16 products, f32 accumulate", "bf16x3": "bf16x3 split products (fp32-class), f32 accumulate"}[a.precision]}))
 
 
 if __name__ == "__main__":
