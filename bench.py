@@ -2,15 +2,17 @@
 """
 Headline benchmark: rendered rays/s at 128 samples/ray, SRN-chairs-shaped 1-view frame (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly
+    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly; N>1 starts its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path (NeRFRenderer.forward -> pnr_render: coarse sampling, fused point network,
 alpha compositing) over one frame of synthetic rays already resident in HBM.  With N ranks each rank renders its
-own contiguous range of an N x larger ray batch (weak scaling) and one RCCL all_gather per step reassembles the
-pixels (pixel_nerf_multiscale_amd.parallel.ShardedRenderer).  Rank 0 prints ONE JSON line with the
-whole-job throughput, the roofline of the dominant kernel (hipEvents around it, recorded by the library on the
-stream it runs on) and a CPU baseline (the oracle restatement timed on this box's host cores, N=1 only).
+own contiguous range of the ray batch and one RCCL all_gather per step reassembles the pixels
+(pixel_nerf_multiscale_amd.parallel.ShardedRenderer): --scaling weak = an N x larger batch (per-GPU work fixed),
+--scaling strong = ONE frame cut into N ranges (BASELINE cfg4: one DTU frame over 8 GPUs).  Rank 0 prints ONE JSON
+line with the whole-job throughput, the roofline of the dominant kernel (hipEvents around it, recorded by the
+library on the stream it runs on), a CPU baseline (the oracle restatement timed on this box's host cores, N=1
+only) and, at N=1, a `secondary` list: the other BASELINE.json shapes timed the same way over a few steps.
 """
 import argparse
 import json
@@ -66,23 +68,26 @@ def executed_ratio(spec, net):
     return flops_per_point(NS, Lz, d_pad) / alg
 
 
-def pmc_traffic_bytes(workload, precision):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary of THIS workload
-    (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh; separate --pmc passes):
+def pmc_traffic(workload, precision):
+    """(bytes, source) — HBM-side bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need
+    separate rocprofv3 --pmc passes, so the figure is read from the committed summary of THIS command on the build the
+    summary names (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh):
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 tallies the
-    128-B requests of wide coalesced reads at 64 B).  None when no summary matches (other workloads / precisions)."""
+    128-B requests of wide coalesced reads at 64 B).  (None, None) when no summary matches."""
     if workload != DEFAULT or precision != "bf16":
-        return None
-    path = os.path.join(ROOT, "profiles", "latest_pmc_bench_default.txt")
+        return None, None
+    rel = os.path.join("profiles", "latest_pmc_bench_default.txt")
     try:
-        vals = {}
-        for line in open(path):
+        vals, build_id = {}, "unknown build"
+        for line in open(os.path.join(ROOT, rel)):
             parts = line.split()
+            if line.startswith("# build:"):
+                build_id = line.split(":", 1)[1].strip()
             if len(parts) >= 4 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[parts[1]] = float(parts[3].split("=")[1])
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"{rel} (committed rocprofv3 --pmc passes of this command, {build_id}); not measured in this run"
     except Exception:
-        return None
+        return None, None
 
 
 def build(workload, precision, device, rank_rays_scale=1, seed=0):
@@ -132,39 +137,22 @@ def cpu_baseline(spec, n_rays_sample, rays):
     return n_rays_sample / dt, dt, res, idx, noise
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU-baseline sample (0 = skip)")
-    args = ap.parse_args()
+def psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 99.0 if mse == 0 else -10 * math.log10(mse)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
 
-    from pixel_nerf_multiscale_amd import _native as N
-    from pixel_nerf_multiscale_amd.parallel import ShardedRenderer
-    spec, net, rend, rays = build(args.workload, args.precision, device, rank_rays_scale=world)
-    R_total = rays.shape[1]                 # world x frame rays; each rank renders R_total / world of them
-    sharded = ShardedRenderer.for_model(rend, net, base_seed=1234)
-
-    # hipEvents around the dominant kernel, recorded by pnr_render on the stream it launches on
+def time_workload(workload, precision, device, steps, warmup, world=1, scaling="weak", dist=None):
+    """W warmup + K timed steps of one workload (barrier + synchronize on both sides, max over ranks).  Returns the
+    per-workload record plus (spec, net, rend, rays) for the parity legs."""
     import ctypes as C
-    evs = []
-    for _ in range(2 * args.steps):
+    from pixel_nerf_multiscale_amd import _native as N
+    from pixel_nerf_multiscale_amd.parallel import ShardedRenderer, shard_range
+    spec, net, rend, rays = build(workload, precision, device, rank_rays_scale=world if scaling == "weak" else 1)
+    R_total = rays.shape[1]                 # weak: world x frame rays; strong: one frame; each rank renders R_total / world
+    sharded = ShardedRenderer.for_model(rend, net, base_seed=1234)
+    evs = []                                # hipEvents around the dominant kernel, recorded by pnr_render on its stream
+    for _ in range(2 * steps):
         h = C.c_void_p()
         N.check(N.lib.pnr_event_create(C.byref(h)), "pnr_event_create")
         evs.append(h)
@@ -174,53 +162,130 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         sharded(rays)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         rend.point_events = (evs[2 * i].value, evs[2 * i + 1].value)
-        rgb, depth = sharded(rays)
+        sharded(rays)
     barrier()
     dt = time.perf_counter() - t0
     rend.point_events = None
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    # dominant kernel (fused point network of the coarse pass): average launch duration over the timed region
+        dt = float(tmax.item())
     kms = []
-    for i in range(args.steps):
+    for i in range(steps):
         ms = C.c_float()
         N.check(N.lib.pnr_event_elapsed_ms(evs[2 * i], evs[2 * i + 1], C.byref(ms)), "pnr_event_elapsed_ms")
         kms.append(ms.value)
     for h in evs:
         N.lib.pnr_event_destroy(h)
     k_ms = float(np.mean(kms))
-    rays_per_rank = R_total // world
+    lo, hi, _ = shard_range(R_total, world, 0)
+    rays_rank0 = hi - lo                    # the events above are rank 0's launches
     fpp = flops_per_point(spec["NS"], sum(c for c, _, _ in spec["lat"]), net.d_in)
-    flops_launch = rays_per_rank * spec["Kc"] * fpp
+    flops_launch = rays_rank0 * spec["Kc"] * fpp
     achieved = flops_launch / (k_ms * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.precision]
+    peak = PEAK_TFLOPS[precision]
+    rec = {
+        "value": R_total * steps / dt, "ms_per_step": dt / steps * 1e3,
+        "config": {"workload": workload, "rays_per_step": R_total, "rays_per_gpu": rays_rank0,
+                   "samples_per_ray": spec["Kc"] + spec["Kf"], "n_coarse": spec["Kc"], "n_fine": spec["Kf"],
+                   "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
+        "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "kernel_ms": k_ms, "flops_per_launch": flops_launch,
+                     # transparency: where the kernel evaluates lin_z as (W_z . Lat) . w over the Hl*Wl texels
+                     # (pnr_pack_mlp_projected) it executes fewer MFMA FLOPs than the reference algorithm's count, which
+                     # is what `achieved` is priced on; frac_executed prices the executed ones
+                     "executed_flops_per_launch": flops_launch * executed_ratio(spec, net),
+                     "frac_executed": achieved / peak * executed_ratio(spec, net)},
+    }
+    return rec, (spec, net, rend, rays)
 
+
+def psnr_vs_fp32_path(workload, precision, device, rend, net, rays, n_sample=2048):
+    """Rendered pixels of the low-precision kernel vs the fp32 HIP path (itself pinned to the reference at 1e-4 by the
+    fixtures) on a strided sample of the frame, identical in-kernel noise.  'final' = the fine pass where there is one."""
+    from hip_util import build_net
+    idx = torch.linspace(0, rays.shape[1] - 1, min(n_sample, rays.shape[1])).long().to(device)
+    sub = rays[:, idx].contiguous()
+    rend.forced_seed = 4321
+    a = rend(net, sub)
+    spec32, net32, rend32, _ = build(workload, "fp32", device)
+    rend32.forced_seed = 4321
+    b = rend32(net32, sub)
+    rend.forced_seed = None
+    lvl = "fine" if rend.using_fine else "coarse"
+    return psnr(a[lvl].rgb.cpu(), b[lvl].rgb.cpu()), psnr(a.coarse.rgb.cpu(), b.coarse.rgb.cpu())
+
+
+# dtype BASELINE.json names per config (cfg5 "fp16 MFMA fc"; bf16 elsewhere)
+SECONDARY = [("srn_chairs_1view_128x128_k64+32", "bf16"), ("nmr_3view_64x64_k64+32", "bf16"),
+             ("dtu_3view_400x300_k128", "bf16"), ("multiscale_cars_2view_128x128_k64+32", "fp16")]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks from here, BEFORE anything touches
+    the GPU in this process (an exec/fork after GPU initialisation is not allowed on the pool), and pass their exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N>1: weak = N x the frame's rays, strong = one frame cut into N ranges; auto = strong for the "
+                         "DTU workload (BASELINE cfg4 is one frame over 8 GPUs), weak otherwise")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--secondary-steps", type=int, default=3, help="timed steps per secondary workload at N=1 (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if args.workload.startswith("dtu") else "weak")
+
+    rec, (spec, net, rend, rays) = time_workload(args.workload, args.precision, device, args.steps, args.warmup, world,
+                                                 scaling, dist)
+    traffic, traffic_src = pmc_traffic(args.workload, args.precision) if world == 1 else (None, None)
+    rec["roofline"]["traffic"] = traffic
+    rec["roofline"]["traffic_source"] = traffic_src
     out = {
         # BASELINE.json's metric on its config; the other shapes (--workload) are labelled as what they are
         "metric": ("rendered rays/sec (128 samples/ray), SRN chairs 1-view" if args.workload == DEFAULT
                    else f"rendered rays/sec ({spec['Kc']}+{spec['Kf']} samples/ray), {args.workload}"),
-        "value": R_total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": rec["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": args.workload, "rays_per_step": R_total, "rays_per_gpu": rays_per_rank,
-                   "samples_per_ray": spec["Kc"] + spec["Kf"], "n_coarse": spec["Kc"], "n_fine": spec["Kf"],
-                   "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
-        "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic_bytes(args.workload, args.precision),
-                     "kernel_ms": k_ms, "flops_per_launch": flops_launch,
-                     # transparency: with one source view and a small latent map the kernel evaluates lin_z as
-                     # (W_z . Lat) . w over the Hl*Wl texels (pnr_pack_mlp_projected) — fewer executed MFMA FLOPs than the
-                     # reference algorithm's count above, which is what `achieved` is priced on
-                     "executed_flops_per_launch": flops_launch * executed_ratio(spec, net)},
+        "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "config": rec["config"], "roofline": rec["roofline"],
     }
     if rank == 0 and world == 1 and args.cpu_rays > 0:
         v, cdt, res, idx, noise = cpu_baseline(spec, args.cpu_rays, rays)
@@ -231,8 +296,22 @@ def main():
         o = rend(net, rays[:, idx.to(device)].contiguous())
         rend.fixed_noise = None
         lvl = "fine" if spec["Kf"] > 0 else "coarse"
-        mse = float(((o[lvl].rgb.cpu() - res[lvl]["rgb"]) ** 2).mean())
-        out["psnr_vs_oracle_db"] = 99.0 if mse == 0 else -10 * math.log10(mse)
+        out["psnr_vs_oracle_db"] = psnr(o[lvl].rgb.cpu(), res[lvl]["rgb"])
+    if rank == 0 and world == 1 and args.secondary_steps > 0 and args.workload == DEFAULT:
+        # the other BASELINE.json shapes, driver-timed in the same run: rays/s, dominant-kernel fraction, PSNR of the
+        # low-precision kernel vs the fp32 HIP path on a 2048-ray sample of the frame
+        del net, rend, rays
+        sec = []
+        for wl, prec in SECONDARY:
+            r2, (spec2, net2, rend2, rays2) = time_workload(wl, prec, device, args.secondary_steps, 1)
+            p_final, p_coarse = psnr_vs_fp32_path(wl, prec, device, rend2, net2, rays2)
+            sec.append({"workload": wl, "dtype": prec, "value": r2["value"], "unit": "rays/s", "steps": args.secondary_steps,
+                        "ms_per_step": r2["ms_per_step"], "kernel_ms": r2["roofline"]["kernel_ms"],
+                        "roofline_frac": r2["roofline"]["frac"], "roofline_frac_executed": r2["roofline"]["frac_executed"],
+                        "psnr_vs_fp32_path_db": p_final, "psnr_coarse_vs_fp32_path_db": p_coarse})
+            del net2, rend2, rays2
+            torch.cuda.empty_cache()
+        out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -109,16 +109,50 @@ PROTOTYPES = {
 }
 
 
+class Stream:
+    """HIP stream handle + the ordinal of the device it belongs to.  Travels through the C ABI as the plain handle
+    (`_as_parameter_`); the ordinal is what the launch guard below needs — handle 0 (the default stream) does not say
+    which device it means."""
+    __slots__ = ("_as_parameter_", "device")
+
+    def __init__(self, handle, device):
+        self._as_parameter_ = handle
+        self.device = device
+
+
+def _guarded(fn):
+    """The library launches on the calling thread's CURRENT HIP device (it never calls hipSetDevice: include/pnr.h
+    'Threading').  The reference picks its GPU with util.get_cuda(gpu_id) and no set_device (eval/eval.py:94), so a
+    tensor may live on cuda:N while the current device is 0: every entry point that takes a stream runs under the
+    stream's device."""
+    def call(*args):
+        s = args[-1] if args else None
+        if isinstance(s, Stream) and s.device != torch.cuda.current_device():
+            with torch.cuda.device(s.device):
+                return fn(*args)
+        return fn(*args)
+    call.__name__ = getattr(fn, "__name__", "pnr_fn")
+    return call
+
+
+class _Lib:
+    pass
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m pixel_nerf_multiscale_amd.build_native` "
             "(hipcc --offload-arch=gfx950).  The render path has no CPU/PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    cdll = C.CDLL(LIB_PATH)
+    lib = _Lib()
+    lib._cdll = cdll
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn = getattr(cdll, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+        takes_stream = bool(args) and args[-1] is _fp and name not in ("pnr_event_destroy",)
+        setattr(lib, name, _guarded(fn) if takes_stream else fn)
     return lib
 
 
@@ -160,4 +194,19 @@ def f32c(t, device=None):
 
 
 def current_stream(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    """torch's current stream on `device` for the C ABI (see Stream)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return Stream(torch.cuda.current_stream(idx).cuda_stream, idx)
+
+
+def same_device(*tensors):
+    """The one device all the given tensors live on; raises when they differ (the library takes raw pointers and
+    cannot tell)."""
+    devs = {t.device for t in tensors if t is not None}
+    if len(devs) != 1:
+        raise ValueError(f"tensors of one native call must share a device, got {sorted(str(d) for d in devs)}")
+    dev = devs.pop()
+    if dev.type != "cuda":
+        raise RuntimeError("libpnr_hip needs tensors on a HIP device (cuda:N); got a CPU tensor")
+    return dev

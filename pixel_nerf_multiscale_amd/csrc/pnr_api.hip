@@ -169,7 +169,8 @@ extern "C" int32_t pnr_point_mlp_bwd(const pnr_params* params, const pnr_mlp* ml
 
 struct RenderWs { uint64_t zc, zf, rgbs, w, rgb, depth, point, total; };
 
-static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t n) {
+// `fine` (may be NULL): the point workspace is shared by both passes, so it is sized for the larger of the two MLPs
+static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t n, const pnr_mlp* fine = nullptr) {
     RenderWs r;
     uint64_t Kc = prm->n_coarse, Kt = (uint64_t)prm->n_coarse + prm->n_fine, off = 0;
     r.zc = off; off += align256(n * Kc * 4);
@@ -178,7 +179,9 @@ static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views
     r.w = off; off += align256(n * Kt * 4);
     r.rgb = off; off += align256(n * 12);
     r.depth = off; off += align256(n * 4);
-    r.point = off; off += align256(point_workspace_bytes(prm, mlp, vw));
+    uint64_t pw = point_workspace_bytes(prm, mlp, vw);
+    if (fine) { uint64_t pf = point_workspace_bytes(prm, fine, vw); if (pf > pw) pw = pf; }
+    r.point = off; off += align256(pw);
     r.total = off + 256;
     return r;
 }
@@ -202,8 +205,8 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     if (n_rays < 0 || rays_per_obj <= 0 || n_rays != rays_per_obj * views->n_objs) return PNR_E_SHAPE;
     if (n_rays == 0) return PNR_OK;
     if (!workspace) return PNR_E_NULL;
-    RenderWs cw = carve(params, coarse, views, n_rays);
-    if (workspace_bytes < cw.total) return PNR_E_WORKSPACE;
+    RenderWs cw = carve(params, coarse, views, n_rays, params->n_fine > 0 ? fine : nullptr);
+    if (workspace_bytes < cw.total) return PNR_E_WORKSPACE;     // pnr_workspace_bytes of BOTH MLPs, the larger one
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t s = (hipStream_t)stream;
     const int Kc = params->n_coarse, Kf = params->n_fine, Kfd = params->n_fine_depth, Kt = Kc + Kf;

@@ -955,11 +955,29 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
     return PNR_OK;
 }
 
-// dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end
+// db (N) += column sums of dY alone: a frozen weight with a trainable bias (needs_input_grad False / True)
+__global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += dY[(size_t)m * ldy + n];
+    atomicAdd(db + n, acc);
+}
+
+// dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end.
+// Either output may be NULL (a frozen parameter): the GEMM kernels need dW, so a bias-only request takes k_col_sums.
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
                       int N, int K, hipStream_t s, int half = 0) {
-    if (!dW || M == 0) return PNR_OK;
+    if ((!dW && !db) || M == 0) return PNR_OK;
+    if (!dW) {
+        const int rows = 2048;
+        hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)((M + rows - 1) / rows)), dim3(256), 0, s, dY, ldy, db,
+                           (int)M, N, rows);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     if (half && N >= 32 && K >= 32 && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx)) {
         const int rows = 1024;
         dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));

@@ -128,11 +128,13 @@ class PixelNeRFNet(torch.nn.Module):
         self.c = c.float().contiguous()
 
     # ------------------------------------------------------------------ native descriptors
-    def resolved_precision(self, mlp=None):
+    def resolved_precision(self, mlp=None, also=None):
+        """Arithmetic of the fc layers for `mlp` (and `also`, the other MLP of the same native call, if any)."""
         p = self.precision
         mlp = mlp if mlp is not None else self.mlp_coarse
         if p == "auto":
-            return "fp16" if mfma_supported(mlp, self) else "fp32"
+            ok = mfma_supported(mlp, self) and (also is None or mfma_supported(also, self))
+            return "fp16" if ok else "fp32"
         if p not in N.PRECISIONS:
             raise ValueError(f"unknown precision {p!r}")
         return p
@@ -273,7 +275,7 @@ class PixelNeRFNet(torch.nn.Module):
             from ..render.autograd import point_mlp_points
             return point_mlp_points(self, mlp, xyz, viewdirs.reshape(SB, B, 3))
         prec = self.resolved_precision(mlp)
-        dev = xyz.device
+        dev = N.same_device(xyz, viewdirs, self.poses)
         xyz_c, vd_c = N.f32c(xyz), N.f32c(viewdirs.reshape(SB, B, 3))
         prm = self.params_struct(None, prec)
         v, k2 = self.views_struct(prec)

@@ -28,7 +28,8 @@ def frame_seed(base_seed, frame_idx):
 
 class ShardedRenderer:
     """render_shard(rays (1, n, 8), ray_index_base, seed) -> (rgb (1,n,3), depth (1,n)) is the per-rank renderer;
-    __call__(rays (1, B, 8)) returns the full (rgb (1,B,3), depth (1,B)) on every rank."""
+    __call__(rays (1, B, 8)) returns the full (rgb (1,B,3), depth (1,B)) on every rank.  gather() is the general
+    form: any list of per-ray outputs, packed into one (rays/world, sum(widths)) fp32 message."""
 
     def __init__(self, render_shard, group=None, base_seed=None):
         self.render_shard = render_shard
@@ -58,24 +59,38 @@ class ShardedRenderer:
             return lvl.rgb, lvl.depth
         return cls(render_shard, **kw)
 
-    def __call__(self, rays):
+    def gather(self, rays, widths):
+        """rays (1, B, 8); render_shard returns len(widths) tensors of (1, n, w) / (1, n) for its range.  ONE
+        all_gather of (ceil(B/world), sum(widths)) fp32; returns the full (1, B, w) / (1, B) tensors on every rank."""
         assert rays.dim() == 3 and rays.shape[0] == 1, "sharded rendering takes one object per call: rays (1, B, 8)"
         B = rays.shape[1]
         lo, hi, per = shard_range(B, self.world, self.rank)
         seed = frame_seed(self.base_seed, self.frame_idx)
         self.frame_idx += 1
-        pix = torch.zeros(per, 4, device=rays.device, dtype=torch.float32)
+        tot = int(sum(widths))
+        pix = torch.zeros(per, tot, device=rays.device, dtype=torch.float32)
         if hi > lo:
-            rgb, depth = self.render_shard(rays[:, lo:hi].contiguous(), lo, seed)
-            pix[: hi - lo, :3] = rgb.reshape(-1, 3)
-            pix[: hi - lo, 3] = depth.reshape(-1)
+            outs = self.render_shard(rays[:, lo:hi].contiguous(), lo, seed)
+            assert len(outs) == len(widths)
+            off = 0
+            for t, w in zip(outs, widths):
+                pix[: hi - lo, off:off + w] = t.reshape(hi - lo, w)
+                off += w
         if self.world > 1:
-            full = torch.empty(self.world * per, 4, device=rays.device, dtype=torch.float32)
+            full = torch.empty(self.world * per, tot, device=rays.device, dtype=torch.float32)
             dist.all_gather_into_tensor(full, pix, group=self.group)
         else:
             full = pix
         full = full[:B]
-        return full[:, :3].reshape(1, B, 3), full[:, 3].reshape(1, B)
+        res, off = [], 0
+        for w in widths:
+            res.append(full[:, off:off + w].reshape(1, B, w) if w > 1 else full[:, off].reshape(1, B))
+            off += w
+        return res
+
+    def __call__(self, rays):
+        rgb, depth = self.gather(rays, [3, 1])
+        return rgb, depth
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -31,6 +31,39 @@ class _RenderWrapper(torch.nn.Module):
         return outputs.toDict()
 
 
+class _ShardedRenderWrapper(torch.nn.Module):
+    """The multi-GPU form of _RenderWrapper: same call signature and return structure, the frame's rays cut into one
+    contiguous range per rank of the process group (parallel.ShardedRenderer), ONE all_gather per call, the full
+    frame returned on every rank.  Replaces nn.DataParallel(wrapped, gpus, dim=1) of nerf.py:367-371."""
+
+    def __init__(self, net, renderer, simple_output, group=None):
+        super().__init__()
+        from ..parallel import ShardedRenderer
+        self.net, self.renderer, self.simple_output = net, renderer, simple_output
+        lvls = lambda: ("fine",) if (simple_output and renderer.using_fine) else \
+            (("coarse",) if simple_output else (("coarse", "fine") if renderer.using_fine else ("coarse",)))
+        self._levels = lvls
+
+        def render_shard(rays, base, seed):
+            renderer.ray_index_base, renderer.forced_seed = base, seed
+            try:
+                out = renderer(net, rays)
+            finally:
+                renderer.ray_index_base, renderer.forced_seed = 0, None
+            return [t for lv in lvls() for t in (out[lv].rgb, out[lv].depth)]
+        self.sharded = ShardedRenderer(render_shard, group=group)
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
+        if want_weights and not self.simple_output:
+            raise NotImplementedError("per-sample weights are not gathered across ranks; render them on one rank")
+        cols = self.sharded.gather(rays, [3, 1] * len(self._levels()))
+        if self.simple_output:
+            return cols[0], cols[1]
+        return {lv: {"rgb": cols[2 * i], "depth": cols[2 * i + 1]} for i, lv in enumerate(self._levels())}
+
+
 class NeRFRenderer(torch.nn.Module):
     def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01,
                  eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None):
@@ -149,11 +182,12 @@ class NeRFRenderer(torch.nn.Module):
 
     def _forward_fused(self, net, rays, want_weights):
         SB, B, _ = rays.shape
-        dev = rays.device
+        dev = N.same_device(rays, net.poses)
         rays_f = N.f32c(rays).reshape(-1, 8)
         n = SB * B
         Kc, Kf = int(self.n_coarse), int(self.n_fine) if self.using_fine else 0
-        prec_c = net.resolved_precision(net.mlp_coarse)
+        # one precision per call: the fused kernel only when BOTH MLPs of this call have a shape it is built for
+        prec_c = net.resolved_precision(net.mlp_coarse, net.mlp_fine if Kf > 0 else None)
         prm = net.params_struct(self, prec_c)
         prm.n_fine = Kf
         prm.n_fine_depth = int(self.n_fine_depth) if Kf > 0 else 0
@@ -185,6 +219,8 @@ class NeRFRenderer(torch.nn.Module):
             o.ev_point_begin, o.ev_point_end = self.point_events
         nz, k4 = self._noise_ptrs(dev)
         nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mc), C.byref(v), n)
+        if mf is not None:      # the point workspace serves both passes: size it for the larger MLP
+            nbytes = max(nbytes, N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mf), C.byref(v), n))
         ws = net.workspace(nbytes, dev)
         N.check(N.lib.pnr_render(C.byref(prm), C.byref(mc), C.byref(mf) if mf is not None else None, C.byref(v),
                                  N.ptr(rays_f), n, B, C.byref(nz), self._seed(), int(self.ray_index_base), C.byref(o),
@@ -259,12 +295,18 @@ class NeRFRenderer(torch.nn.Module):
                    sched=conf.get_list("sched", None))
 
     def bind_parallel(self, net, gpus=None, simple_output=False):
-        """Callable (rays, want_weights) bound to `net` (nerf.py:354-371).  The reference wraps it in
-        nn.DataParallel when several gpus are given; here multi-GPU is one process per GPU
-        (pixel_nerf_multiscale_amd.parallel.ShardedRenderer over RCCL), so `gpus` with more than one id is
-        rejected rather than silently running on one device."""
+        """Callable (rays, want_weights) bound to `net` (nerf.py:354-371; callers eval/eval.py:151,
+        eval/gen_video.py:110 pass args.gpu_id).  The reference wraps it in nn.DataParallel(dim=1) when several gpus
+        are listed; here multi-GPU is one process per GPU: when the script runs under torch.distributed.run (a
+        process group exists, world > 1) the returned callable shards every call's rays over the ranks and returns
+        the full frame on each (RCCL all_gather over xGMI).  Several ids WITHOUT a process group cannot be served by
+        one process: warn and render on this process's device."""
+        import torch.distributed as dist
         if gpus is not None and len(gpus) > 1:
-            raise NotImplementedError(
-                "single-process multi-GPU (nn.DataParallel) is replaced by one process per GPU: launch with "
-                "torch.distributed.run and wrap with pixel_nerf_multiscale_amd.parallel.ShardedRenderer")
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return _ShardedRenderWrapper(net, self, simple_output=simple_output)
+            import warnings
+            warnings.warn(f"bind_parallel(gpus={list(gpus)}): single-process multi-GPU (nn.DataParallel) is replaced by one "
+                          "process per GPU — start the script with torch.distributed.run to use them; rendering on one "
+                          "device now")
         return _RenderWrapper(net, self, simple_output=simple_output)

@@ -54,6 +54,11 @@ CASES = {
                                  lat=[(64, 16, 16), (64, 16, 16), (128, 8, 8), (256, 4, 4)],
                                  image=(32, 32), focal=33.0, N=16, Kc=16, Kf=8, Kfd=4,
                                  z_near=0.8, z_far=1.8, radius=1.3),
+    # BASELINE cfg4 shape (DTU rs_dtu_4): 3 views, 400x300 image, 19x25 latent (T = 475 texels: the general gather path of
+    # the fused kernel at NS=3), 128 coarse samples in disparity, black background; edge rays leave the source frusta
+    "full_dtu_ns3": _case(seed=34, d_hidden=512, lat=[(256, 19, 25)], image=(400, 300), focal=360.0, NS=3,
+                          N=16, Kc=128, Kf=0, Kfd=0, lindisp=True, white_bkgd=False, z_near=0.1, z_far=5.0,
+                          radius=2.0, edge=True),
 }
 
 
@@ -169,7 +174,7 @@ def make_latents(spec):
 # ----------------------------------------------------------------------------- backward cases
 GRAD_CASES = ["tiny_ns1", "tiny_ns2_lindisp_black", "tiny_ns2_codeview", "tiny_multiscale_ns2", "tiny_sb2_ns2",
               "tiny_nodepth", "tiny_onlydepth", "tiny_nofine_mlp", "tiny_max_combine", "tiny_ns1_coarse_only",
-              "full_ns1", "full_ns3", "full_multiscale_ns2"]
+              "full_ns1", "full_ns3", "full_multiscale_ns2", "full_dtu_ns3"]
 GRAD_SAMPLES = 512      # entries kept per gradient tensor larger than this
 
 
@@ -210,3 +215,15 @@ def load_fixture(name):
     fx = {k: z[k] for k in z.files}
     fx["spec"] = json.loads(str(fx["spec_json"]))
     return fx
+
+
+def load_rays_fixture():
+    """tests/golden/gen_rays.npz (tools/gen_golden_rays.py: the reference's own util.gen_rays outputs): list of dicts."""
+    z = np.load(os.path.join(GOLDEN_DIR, "gen_rays.npz"), allow_pickle=False)
+    cases = []
+    for name in str(z["names"]).split(","):
+        c = z[f"{name}__c"]
+        cases.append(dict(name=name, poses=z[f"{name}__poses"], cams=z[f"{name}__cams"], W=int(z[f"{name}__WH"][0]),
+                          H=int(z[f"{name}__WH"][1]), focal=z[f"{name}__focal"], c=None if c.size == 0 else c,
+                          z_near=float(z[f"{name}__z"][0]), z_far=float(z[f"{name}__z"][1]), rays=z[f"{name}__rays"]))
+    return cases

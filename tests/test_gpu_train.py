@@ -284,3 +284,31 @@ def test_bf16_product_mode_gradients(name):
         rel = float((a - b).norm()) / nb
         cos = float((a @ b) / (a.norm() * b.norm()))
         assert rel <= 0.15 and cos >= 0.99, (k, rel, cos)
+
+
+def test_frozen_weights_still_give_bias_gradients():
+    """needs_input_grad False for a weight, True for its bias: the bias gradient must still be the reference's
+    (the GEMM kernels need dW; the bias-only request takes the column-sum kernel)."""
+    name = "tiny_ns2_codeview"
+    gfx = gu.load_grad_fixture(name)
+    fx, spec, net, rend = hu.setup(name)
+    net.train()
+    for mlp in (net.mlp_coarse, net.mlp_fine):
+        for k, p in mlp.named_parameters():
+            if k.endswith("weight"):
+                p.requires_grad_(False)
+    rays = torch.from_numpy(fx["rays"]).cuda()
+    out = rend(net, rays, want_weights=True)
+    G = {k: torch.from_numpy(v).cuda() for k, v in gu.make_loss_weights(spec).items()}
+    loss = sum((out[t].rgb * G[f"{t}_rgb"]).sum() + (out[t].depth * G[f"{t}_depth"]).sum()
+               + (out[t].weights * G[f"{t}_weights"]).sum() for t in ("coarse", "fine"))
+    loss.backward()
+    grads = {}
+    for which, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)):
+        for k, p in mlp.named_parameters():
+            if k.endswith("weight"):
+                assert p.grad is None
+            else:
+                assert p.grad is not None and float(p.grad.abs().max()) > 0, k
+                grads[f"{which}.{k}"] = p.grad.cpu().numpy()
+    compare_grads(grads, {k: v for k, v in gfx.items() if k.split("__")[0] in grads or k == "loss"}, RTOL, name)

@@ -107,8 +107,9 @@ def test_renderer_surface_and_schedule():
     assert (r.n_coarse, r.n_fine, int(r.last_sched)) == (32, 16, 2)
     d = NeRFRenderer()
     assert (d.n_coarse, d.n_fine, d.white_bkgd, d.lindisp, d.sched) == (128, 0, False, False, None)
-    with pytest.raises(NotImplementedError):
-        d.bind_parallel(None, gpus=[0, 1])
+    with pytest.warns(UserWarning):          # several ids, no process group: one device, with a warning (a16)
+        w = d.bind_parallel(None, gpus=[0, 1])
+    assert type(w).__name__ == "_RenderWrapper"
 
 
 def test_container_modules_do_not_evaluate_in_pytorch():
@@ -171,3 +172,21 @@ def test_training_and_projection_switches_host_logic():
     assert N.lib.pnr_sample_fine_bwd(None, None, 4, 8, 4, 2, 0.01, None, 0, 0, None, None, None, None) == -1
     assert N.lib.pnr_packed_mlp_projected_bytes(None, None) == 0
     assert N.lib.pnr_pack_mlp_projected(None, None, N.PNR_BF16, None, 0, None) == -1
+
+
+def test_gen_rays_mirror_matches_reference_fixture():
+    """N1: util.gen_rays / unproj_map / pose_spherical (host mirrors of reference util.py:118-148,243-281,314-328) against
+    the reference's own outputs (tests/golden/gen_rays.npz): both principal-point conventions, (fx, fy) focal,
+    non-square and odd sizes, a batch of poses."""
+    import numpy as np
+    import torch
+    import golden_util as gu
+    from pixel_nerf_multiscale_amd import util
+    for cs in gu.load_rays_fixture():
+        poses = torch.stack([util.pose_spherical(*cam) for cam in cs["cams"]])
+        assert np.abs(poses.numpy() - cs["poses"]).max() <= 1e-6, cs["name"]
+        c = None if cs["c"] is None else torch.from_numpy(cs["c"])
+        rays = util.gen_rays(torch.from_numpy(cs["poses"]), cs["W"], cs["H"], torch.from_numpy(cs["focal"]), cs["z_near"],
+                             cs["z_far"], c=c)
+        assert rays.shape == cs["rays"].shape
+        assert np.abs(rays.numpy() - cs["rays"]).max() <= 2e-6, cs["name"]
