@@ -56,16 +56,21 @@ def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
 
 
 def executed_ratio(spec, net):
-    """Executed / algorithmic MFMA FLOPs per point of the fused kernel for this configuration."""
+    """Executed / algorithmic MFMA FLOPs per point of the fused kernel for this configuration (stream layout of
+    csrc/point_mfma.hip: 32-wide k-steps; lin_in padded to 64 / 96 inputs; a bias k-step per block + one before lin_out;
+    lin_out on a 16-row fragment; where the last latent level is projected, lin_z over its texels instead of its channels)."""
     NS, L = spec["NS"], sum(c for c, _, _ in spec["lat"])
     d_in = 78 if spec["use_code_viewdirs"] else 42
+    H, nb, cl = 512, 5, 3
     alg = flops_per_point(NS, L, d_in)
     T = spec["lat"][-1][1] * spec["lat"][-1][2]                # the projected (last) level
     projected = (net.project_latent and spec["SB"] == 1 and NS <= 8 and spec["lat"][-1][0] == 256 and (L - 256) % 256 == 0
                  and T <= 256)
-    Lz = (L - 256) + ((T + 15) // 16) * 16 if projected else L
-    d_pad = ((d_in + 2 + 15) // 16) * 16                      # lin_in k is padded to 16 (bias folded into 2 spare slots)
-    return flops_per_point(NS, Lz, d_pad) / alg
+    Lz = (L - 256) + ((T + 31) // 32) * 32 if projected else L
+    S_in = 3 if d_in == 78 else 2
+    per_view = 32 * S_in * H + cl * (Lz * H + 32 * H + 2 * H * H)
+    per_pt = (nb - cl) * (32 * H + 2 * H * H) + 32 * H + 16 * H
+    return 2 * (NS * per_view + per_pt) / alg
 
 
 def pmc_traffic(workload, precision):

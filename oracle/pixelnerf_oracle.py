@@ -23,7 +23,7 @@ import torch
 def sample_coarse(rays, n_coarse, lindisp, noise_c):
     near, far = rays[:, 6:7], rays[:, 7:8]
     step = 1.0 / n_coarse
-    z_steps = torch.linspace(0, 1 - step, n_coarse, dtype=torch.float32)[None].repeat(rays.shape[0], 1)
+    z_steps = torch.linspace(0, 1 - step, n_coarse, dtype=rays.dtype)[None].repeat(rays.shape[0], 1)
     z_steps = z_steps + noise_c * step
     if not lindisp:
         return near * (1 - z_steps) + far * z_steps
@@ -101,10 +101,10 @@ def encode_cameras(poses_c2w, focal, c, W, H):
 def positional_encoding(x, num_freqs=6, freq_factor=1.5):
     """[x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...], f_k = freq_factor * 2^k; pi/2 in fp32."""
     freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
-    fr = torch.repeat_interleave(freqs, 2).view(1, -1, 1)
+    fr = torch.repeat_interleave(freqs, 2).view(1, -1, 1).to(x.dtype)
     ph = torch.zeros(2 * num_freqs)
     ph[1::2] = math.pi * 0.5
-    ph = ph.view(1, -1, 1)
+    ph = ph.view(1, -1, 1).to(x.dtype)     # the fp32 buffer's value also when a test runs this file in float64
     embed = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
     embed = torch.sin(torch.addcmul(ph, embed, fr))
     return torch.cat((x, embed.view(x.shape[0], -1)), dim=-1)

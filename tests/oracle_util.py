@@ -46,3 +46,15 @@ def maxdiff(a, b):
     d = np.abs(a - b)
     d[both_nan] = 0
     return float(np.nanmax(d)) if not np.isnan(d).any() else float("nan")
+
+
+def oracle_points_f64(fx, tag):
+    """The fixture's model call `tag` ('coarse' / 'fine') recomputed by the oracle restatement in float64: the arbiter
+    between two fp32 results (the reference's and the HIP path's) that differ by summation order."""
+    spec, cam, lat, sd_c, sd_f = oracle_setup(fx)
+    sd = sd_c if (tag == "coarse" or sd_f is None) else sd_f
+    d = torch.float64
+    return orc.point_forward({k: v.to(d) for k, v in sd.items()}, tuple(t.to(d) for t in cam), [m.to(d) for m in lat],
+                             torch.from_numpy(fx[f"pts_xyz_{tag}"]).to(d), torch.from_numpy(fx[f"pts_dirs_{tag}"]).to(d),
+                             spec["NS"], use_code_viewdirs=spec["use_code_viewdirs"], n_blocks=spec["n_blocks"],
+                             combine_layer=spec["combine_layer"], combine_type=spec["combine_type"]).numpy()

@@ -7,7 +7,7 @@ import torch
 
 import golden_util as gu
 from oracle import pixelnerf_oracle as orc
-from oracle_util import maxdiff, noise_from_fixture, oracle_render
+from oracle_util import maxdiff, noise_from_fixture, oracle_points_f64, oracle_render
 
 pytestmark = pytest.mark.gpu
 ALL = sorted(gu.CASES)
@@ -47,6 +47,13 @@ def test_point_mlp_fp32_matches_reference(name):
         # sigma = a 512-term sum with O(50) partial sums scaled x20 by the synthetic lin_out: fp32 summation-order
         # noise alone is ~5e-4 absolute; it enters the render as delta*sigma with delta ~ 0.02
         assert (np.abs(o[..., 3] - ref[..., 3]) <= 1e-3 + 1e-4 * np.abs(ref[..., 3])).all(), tag
+        # ... and that is what it is: against the float64 recomputation of the same points the HIP result sits in the
+        # same band as the reference's own fp32 result (measured |ref - f64| on sigma: 5e-5 … 4e-4, 1.2e-3 on the DTU
+        # case whose coordinates reach 40 units) — both fp32 sums bracket the float64 value
+        t64 = oracle_points_f64(fx, tag)
+        e_ref, e_hip = np.abs(ref - t64), np.abs(o - t64)
+        assert e_hip[..., 3].max() <= 4.0 * max(e_ref[..., 3].max(), 1e-4), (tag, e_hip[..., 3].max(), e_ref[..., 3].max())
+        assert e_hip[..., :3].max() <= 4.0 * max(e_ref[..., :3].max(), 1e-5), (tag, e_hip[..., :3].max(), e_ref[..., :3].max())
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -192,11 +199,22 @@ def _psnr(a, b):
     return 99.0 if mse == 0 else -10.0 * np.log10(mse)
 
 
-# Low-precision tolerance: the reference has no bf16/fp16 numerics; the bound is PSNR(build, fp32
-# reference) on the rendered pixels — the north-star's 0.05 dB budget is >= 42.4 dB for uncorrelated error; the
-# 16-ray fixtures are small samples, so the per-fixture floors sit a little below the 50 dB frame-level floor that
-# test_mfma_frame_psnr enforces on 4096 rays.
-@pytest.mark.parametrize("prec,floor_pts,floor_px", [("bf16", 52.0, 46.0), ("fp16", 68.0, 62.0)])
+# Low-precision bound — ONE statement, enforced by every test below: the reference has no bf16/fp16
+# numerics, so the bound is PSNR(low-precision render, fp32 render of the same rays with the same noise) on the rendered
+# pixels of EITHER pass:   bf16 >= 42.4 dB   (the north-star's 0.05 dB budget for an uncorrelated error),
+#                          fp16 >= 58 dB     (what precision="auto" selects).
+# Point level (the network's rgb before compositing) both kernels are shape-independent: bf16 >= 52 dB, fp16 >= 68 dB
+# (measured 60-62 / 78-79 dB on SRN, NMR and DTU shapes alike, tools/dev/bf16_gap.py); what differs between shapes is the
+# compositing stage's gain on the sigma error (DTU: disparity steps of up to 2 units -> 44-45 dB in bf16).
+# The end-to-end FINE pass draws its sample positions from the low-precision coarse weights: a cdf entry moving across
+# a draw u makes that importance sample jump a bin (SURVEY §8c caveat; the reference's own CPU and GPU cumsum differ the
+# same way), so there the north-star budget itself (42.4 dB) is the floor for both precisions.
+BF16_FLOOR_DB, FP16_FLOOR_DB = 42.4, 58.0
+FLOOR_DB = {"bf16": BF16_FLOOR_DB, "fp16": FP16_FLOOR_DB}
+FINE_E2E_FLOOR_DB = 42.4
+
+
+@pytest.mark.parametrize("prec,floor_pts,floor_px", [("bf16", 52.0, BF16_FLOOR_DB), ("fp16", 68.0, FP16_FLOOR_DB)])
 @pytest.mark.parametrize("name", FULL)
 def test_mfma_matches_reference(name, prec, floor_pts, floor_px):
     from hip_util import setup
@@ -212,7 +230,7 @@ def test_mfma_matches_reference(name, prec, floor_pts, floor_px):
         assert rel.max() <= (0.25 if prec == "bf16" else 0.05), tag          # sigma logits are x20 in the fixtures
     out = rend(net, _dev(fx["rays"]), want_weights=True)
     for lvl in levels:
-        assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= floor_px, lvl
+        assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= (floor_px if lvl == "coarse" else FINE_E2E_FLOOR_DB), lvl
         # fine pass: its sample positions are drawn from the LOW-PRECISION coarse weights/depth, so a sample can land in
         # a neighbouring bin and move one ray's weights discontinuously (SURVEY §8c caveat) — looser bound there
         tol_w = {("bf16", "coarse"): 0.05, ("bf16", "fine"): 0.15, ("fp16", "coarse"): 0.01, ("fp16", "fine"): 0.03}[(prec, lvl)]
@@ -284,7 +302,7 @@ def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, ima
         assert _psnr(outs["proj"][lvl].rgb.cpu(), ref) >= floor
         assert _psnr(outs["gen"][lvl].rgb.cpu(), ref) >= floor
         assert _psnr(outs["proj"][lvl].rgb.cpu(), outs["gen"][lvl].rgb.cpu()) >= floor_self
-    assert _psnr(outs["proj"].fine.rgb.cpu(), outs["fp32"].fine.rgb.cpu()) >= 36.0
+    assert _psnr(outs["proj"].fine.rgb.cpu(), outs["fp32"].fine.rgb.cpu()) >= FINE_E2E_FLOOR_DB
     # re-encoding (new latent) must re-pack: same weights, different map -> different output, still right
     net = build_net(spec, poses, "cuda", prec)
     rend = build_renderer(spec); rend.forced_seed = 7
@@ -368,21 +386,36 @@ def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv, comb):
     the fixtures do not hold at d_hidden=512: several objects per call, 2/4 source views, coded viewdirs."""
     from hip_util import build_net, build_renderer
     import golden_util as gu
-    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=200, use_code_viewdirs=cv, seed=70 + NS + SB, combine_type=comb)
+    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=2000, use_code_viewdirs=cv, seed=70 + NS + SB, combine_type=comb)
     rays_np, poses = gu.make_inputs(spec)
     rays = torch.from_numpy(rays_np).cuda()
-    outs = {}
+    outs, fine_fixed = {}, {}
+    z32 = None
     for p in ("fp32", "fp16", "bf16"):
         net = build_net(spec, poses, "cuda", p)
         rend = build_renderer(spec)
         rend.forced_seed = 5
+        rend.keep_samples = True
         o = rend(net, rays, want_weights=True)
         outs[p] = (o.fine.rgb.cpu(), o.fine.weights.cpu(), o.coarse.rgb.cpu())
-    assert outs["fp32"][0].shape == (SB, 200, 3)
-    assert _psnr(outs["fp16"][2], outs["fp32"][2]) >= 58.0 and _psnr(outs["bf16"][2], outs["fp32"][2]) >= 42.0     # (max-combine: 61.8 / 43.6)
-    # fine pass: a low-precision coarse weight can move a cdf entry across a draw u -> that importance sample jumps a
-    # bin (SURVEY §8c caveat), so the end-to-end fine floor is lower than the coarse one
-    assert _psnr(outs["fp16"][0], outs["fp32"][0]) >= 46.0 and _psnr(outs["bf16"][0], outs["fp32"][0]) >= 36.0
+        if p == "fp32":
+            z32 = o.fine.z                                               # (SB, N, Kc + Kf)
+        # the fine pass at the fp32 path's sample positions (SURVEY §8c: compare the fine pass with z_samp injected as well as
+        # end-to-end): same points through this precision's fine MLP, composited by the stage kernel
+        K = z32.shape[-1]
+        xyz = (rays[:, :, None, :3] + z32[..., None] * rays[:, :, None, 3:6]).reshape(SB, -1, 3).contiguous()
+        vd = rays[:, :, None, 3:6].expand(-1, -1, K, -1).reshape(SB, -1, 3).contiguous()
+        pts = net(xyz, coarse=False, viewdirs=vd).reshape(-1, K, 4).contiguous()
+        _, rgb_f, _ = rend._composite_native(rays.reshape(-1, 8), z32.reshape(-1, K).contiguous(), pts)
+        fine_fixed[p] = rgb_f.cpu().reshape(SB, -1, 3)
+    assert outs["fp32"][0].shape == (SB, 2000, 3)
+    assert _psnr(fine_fixed["fp32"], outs["fp32"][0]) >= 90.0                  # the injected route reproduces the fp32 render
+    for p in ("fp16", "bf16"):
+        assert _psnr(outs[p][2], outs["fp32"][2]) >= FLOOR_DB[p], (p, "coarse")
+        assert _psnr(fine_fixed[p], fine_fixed["fp32"]) >= FLOOR_DB[p], (p, "fine pass at the fp32 sample positions")
+        # end to end the fine pass resamples from the low-precision coarse weights (bins can flip): the north-star budget for
+        # the mean-combine every BASELINE config uses; max-combine (no config uses it; no averaging over views) sits lower
+        assert _psnr(outs[p][0], outs["fp32"][0]) >= (FINE_E2E_FLOOR_DB if comb == "average" else 40.0), (p, "fine, end to end")
 
 
 def test_render_image_from_camera_equals_forward_on_host_rays():
@@ -519,12 +552,6 @@ def test_c_abi_error_codes():
     assert call(p=p5) == -2
     assert N.lib.pnr_composite(N.ptr(rays), rays.data_ptr() + 4, rays.data_ptr() + 4, 2, 2, 0, None, N.ptr(rgb), N.ptr(dep), s) == -5
     torch.cuda.synchronize()
-
-
-# One stated low-precision bound, enforced on every frame-level test below: PSNR(low-precision render,
-# fp32 render) >= 42.4 dB for bf16 — the north-star's 0.05 dB budget for an uncorrelated error — and
-# >= 58 dB for fp16 (what precision="auto" selects).
-BF16_FLOOR_DB, FP16_FLOOR_DB = 42.4, 58.0
 
 
 @pytest.mark.parametrize("prec,floor", [("bf16", BF16_FLOOR_DB), ("fp16", FP16_FLOOR_DB)])

@@ -50,7 +50,7 @@ def test_gradients_match_reference(name):
     # the taped forward is the fp32 path: same tolerance as the inference-precision parity tests
     assert np.abs(out.coarse.rgb.detach().cpu().numpy() - fx["coarse_rgb"]).max() <= 1e-4
     assert abs(loss - float(gfx["loss"])) <= 1e-3 * max(1.0, abs(float(gfx["loss"])))
-    compare_grads(grads, gfx, RTOL, name)
+    compare_grads(grads, gfx, RTOL, name, truth=lambda: oracle_grads(fx, torch.float64)[1])
 
 
 @pytest.mark.parametrize("name", ["full_ns1", "full_ns3", "full_multiscale_ns2", "tiny_ns2_codeview", "tiny_max_combine"])

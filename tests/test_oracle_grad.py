@@ -9,19 +9,23 @@ from oracle_util import noise_from_fixture, oracle_setup
 from oracle import pixelnerf_oracle as orc
 
 
-def oracle_grads(fx):
-    """loss and {key: grad} of the oracle render for the fixture's inputs and make_loss_weights cotangents."""
+def oracle_grads(fx, dtype=torch.float32):
+    """loss and {key: grad} of the oracle render for the fixture's inputs and make_loss_weights cotangents.
+    dtype=torch.float64 runs the same restatement in double precision: the arbiter when two fp32 results (the
+    reference's and the HIP path's) differ by more than the tolerance on an ill-conditioned case."""
     spec, cam, lat, sd_c, sd_f = oracle_setup(fx)
-    lat = [m.clone().requires_grad_(True) for m in lat]
+    cam = tuple(t.to(dtype) for t in cam)
+    lat = [m.to(dtype).clone().requires_grad_(True) for m in lat]
     for sd in (sd_c, sd_f):
         if sd is not None:
             for k in sd:
-                sd[k] = sd[k].clone().requires_grad_(True)
-    out = orc.render(sd_c, sd_f, cam, lat, torch.from_numpy(fx["rays"]), spec["NS"], spec["Kc"], spec["Kf"], spec["Kfd"],
-                     spec["depth_std"], spec["white_bkgd"], spec["lindisp"], noise_from_fixture(fx),
+                sd[k] = sd[k].to(dtype).clone().requires_grad_(True)
+    noise = {k: v.to(dtype) for k, v in noise_from_fixture(fx).items()}
+    out = orc.render(sd_c, sd_f, cam, lat, torch.from_numpy(fx["rays"]).to(dtype), spec["NS"], spec["Kc"], spec["Kf"], spec["Kfd"],
+                     spec["depth_std"], spec["white_bkgd"], spec["lindisp"], noise,
                      use_code_viewdirs=spec["use_code_viewdirs"], n_blocks=spec["n_blocks"],
                      combine_layer=spec["combine_layer"], combine_type=spec["combine_type"])
-    G = {k: torch.from_numpy(v) for k, v in gu.make_loss_weights(spec).items()}
+    G = {k: torch.from_numpy(v).to(dtype) for k, v in gu.make_loss_weights(spec).items()}
     loss = 0.0
     for tag in ("coarse", "fine") if spec["Kf"] > 0 else ("coarse",):
         loss = loss + (out[tag]["rgb"] * G[f"{tag}_rgb"]).sum() + (out[tag]["depth"] * G[f"{tag}_depth"]).sum() \
@@ -38,10 +42,14 @@ def oracle_grads(fx):
     return float(loss.item()), grads
 
 
-def compare_grads(got, gfx, rtol, what):
-    """Every gradient tensor of the fixture: sampled entries within rtol of the tensor's scale, norm within rtol."""
+def compare_grads(got, gfx, rtol, what, truth=None):
+    """Every gradient tensor of the fixture: sampled entries within rtol of the tensor's scale, norm within rtol.
+    `truth` (optional, callable -> {key: float64 gradient}): where `got` and the reference's fp32 gradient differ by
+    more than rtol, `got` must be within rtol of the float64 recomputation instead — on ill-conditioned cases (disparity
+    sampling with step sizes from 1e-3 to > 1) the reference's own fp32 backward is 1e-3 of scale away from it."""
     keys = [k for k in gfx if k != "loss" and not k.endswith("__norm")]
     assert keys
+    t64 = None
     for k in keys:
         assert k in got, f"{what}: no gradient for {k}"
         g = np.asarray(got[k], dtype=np.float64).reshape(-1)
@@ -50,6 +58,15 @@ def compare_grads(got, gfx, rtol, what):
         norm = float(gfx[k + "__norm"])
         scale = max(norm / np.sqrt(g.size), float(np.abs(ref).max()), 1e-12)
         err = float(np.abs(g[idx] - ref).max())
+        ok = err <= rtol * scale + 1e-7 and abs(np.linalg.norm(g) - norm) <= rtol * norm + 1e-7
+        if not ok and truth is not None:
+            t64 = t64 if t64 is not None else truth()
+            t = np.asarray(t64[k], dtype=np.float64).reshape(-1)
+            err_t, err_ref_t = float(np.abs(g - t).max()), float(np.abs(t[idx] - ref).max())
+            assert err_t <= rtol * scale + 1e-7, (f"{what} {k}: {err_t:.3e} from the float64 gradient (reference fp32: "
+                                                   f"{err_ref_t:.3e}), scale {scale:.3e}")
+            assert abs(np.linalg.norm(g) - np.linalg.norm(t)) <= rtol * np.linalg.norm(t) + 1e-7, f"{what} {k}: norm"
+            continue
         assert err <= rtol * scale + 1e-7, f"{what} {k}: max err {err:.3e} vs scale {scale:.3e}"
         assert abs(np.linalg.norm(g) - norm) <= rtol * norm + 1e-7, f"{what} {k}: norm {np.linalg.norm(g)} vs {norm}"
 
@@ -61,3 +78,21 @@ def test_oracle_autograd_matches_reference_gradients(name):
     loss, grads = oracle_grads(fx)
     assert abs(loss - float(gfx["loss"])) <= 1e-4 * max(1.0, abs(float(gfx["loss"])))
     compare_grads(grads, gfx, 2e-4, name)
+
+
+def test_reference_fp32_gradients_vs_float64_on_the_disparity_case():
+    """Why test_gpu_train arbitrates with float64 on full_dtu_ns3: the reference's OWN fp32 backward is ~1e-3 of a
+    tensor's scale away from the float64 gradient there (128 disparity samples over z in [0.01, 40]: step sizes from
+    1e-3 to > 10), well within 5e-4 on a well-conditioned case."""
+    def worst(name):
+        fx, gfx = gu.load_fixture(name), gu.load_grad_fixture(name)
+        _, g64 = oracle_grads(fx, torch.float64)
+        w = 0.0
+        for k in [k for k in gfx if k != "loss" and not k.endswith("__norm")]:
+            g = g64[k].reshape(-1)
+            ref = gfx[k].astype(np.float64)
+            scale = max(float(gfx[k + "__norm"]) / np.sqrt(g.size), float(np.abs(ref).max()), 1e-12)
+            w = max(w, float(np.abs(g[gu.grad_sample_index(k, g.size)] - ref).max()) / scale)
+        return w
+    assert 5e-4 < worst("full_dtu_ns3") < 5e-3
+    assert worst("full_ns3") < 5e-4

@@ -11,7 +11,7 @@ res = {l: [] for l in libs}
 for rnd in range(3):
     for l in libs:
         env = dict(os.environ, PNR_LIB=os.path.join(ROOT, l))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--cpu-rays", "0"] + wl,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--cpu-rays", "0", "--secondary-steps", "0"] + wl,
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         res[l].append(json.loads(out)["roofline"]["kernel_ms"])
 for l in libs:

@@ -8,7 +8,7 @@ import bench
 from pixel_nerf_multiscale_amd import _native as N
 wl = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
 spec, net, rend, rays = bench.build(wl, "bf16", torch.device("cuda"))
-fn = N.lib.pnr_debug_stamps
+fn = N.lib._cdll.pnr_debug_stamps
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 16)()
 for _ in range(2): rend(net, rays)
@@ -19,7 +19,10 @@ import time
 torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(5): rend(net, rays)
 torch.cuda.synchronize(); print("ms/frame (stamped build)", (time.perf_counter()-t0)/5*1e3)
-names = ["tile total", "prologue(geom+posenc)", "lin_in+gather", "lin_z", "snapshot", "bias stage", "chunk loop", "lin_out+store", "  [geom loads+project]", "  [dma issue]", "  [barrier]", "-"]
+names = ["tile total", "prologue(geom+posenc)", "lin_in+gather/taps", "lin_z groups (gather + x-stages)", "-", "-", "resblock asm (lin_z tail + bias + 16 chunks)", "bias + lin_out + store"]
 tot = buf[0]
+n_tiles = rays.shape[1] * spec["Kc"] // 128
 for i, n in enumerate(names):
-    print(f"{n:24s} {buf[i]/tot*100:6.2f}%   cycles/wave/tile = {buf[i]/ (3*1024*64):10.0f}")
+    if n != "-":
+        print(f"{n:48s} {buf[i]/tot*100:6.2f}%   cycles/wave/tile = {buf[i]/ (3*4*n_tiles):10.0f}")
+print(f"in-kernel clock {buf[12]/buf[13]*0.1:.3f} GHz (stamped build)")

@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """
-Generates pixel_nerf_multiscale_amd/csrc/resblock_asm.inc: the resblock of the fused point kernel
-(x += fc_1(relu(fc_0(relu(x)))) + biases, reference resnetfc.py:53-62) as ONE hand-scheduled gfx950 asm block per
-MFMA dtype.  hipcc's version of the same loop runs ~3300 cycles per 64-MFMA chunk (AGPR-tile parking, per-MFMA
-waits, ~50 scalar ops per chunk); this schedule runs ~2400 (tools/dev/ubench).
+Generates pixel_nerf_multiscale_amd/csrc/resblock_asm.inc: the hand-scheduled gfx950 asm blocks of the fused point
+kernel (csrc/point_mfma.hip) — every MFMA of the network is issued from here:
 
-Contract with k_point_mfma (csrc/point_mfma.hip, PNR_ASM_RESBLOCK):
-  * x tiles are pinned: tile t = a[16t : 16t+15] (operands %0..%15, "+{a[..]}").
-  * entry: the next stage to consume (this block's fc_1-bias stage) is published, DMA of the two stages after it is
-    in flight, nothing is assumed about the A-fragment registers (they are reloaded here).
-  * in/out scalars: %16 st_slot, %17 ld_idx, %18 ld_slot, %19 ld_rep, %20 ld_wrap   (loader cursor, see issue_piece)
-  * inputs: %21 cfg = P1 | (P1+P2)<<12 | NS<<24 (loader's view of the stream), %22 stream base (s64), %23 ring LDS base + wave*4096 (s),
-            %24 ring LDS base + lane*16 (v), %25 DMA lane offset wave*4096 + lane*16 (v),
-            %26 LDS address of fc_0.bias[block] + 16*(lane>>5) (v), %27 bias B-fragment dword 0 (v),
-            %28 lin_z B image address (v), %29 lin_z cfg2 = n_lds | bias<<8, 0 = no lin_z prefix (s)
-  * exit: all LDS reads drained, accumulators readable, 65 stages consumed, cursor advanced.
-Register use inside (all declared as clobbers): v10-13 slot read bases, v14 bias address, v15 DMA lane offset,
-v16-19 bias B fragment, v40-55 and v72-87 the two chunk accumulators (VGPR-form MFMA), v60-67 relu(h) fragments, v68-71 temps,
-v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 tiles x 2 k-steps x 4), s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
+  PNR_XSTAGES_ASM_{BF16,F16}    n k-steps 'x += W . B' with B = a k-step image in the wave's LDS buffer (LIN_IN, lin_z)
+  PNR_RESBLOCK_ASM_{BF16,F16}   one block: [lin_z k-steps] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62)
+  PNR_LINOUT_ASM_{BF16,F16}     last fc_1 bias + lin_out(relu(x))                                           (resnetfc.py:235)
+  PNR_VIEWSPILL_ASM / PNR_VIEWREDUCE_ASM   park / reduce the per-view residual streams                       (util.py:466-476)
+
+MFMA shape: v_mfma_f32_16x16x32_{bf16,f16}, TWO per 1-KiB weight fragment (the wave's 32 points = two 16-column
+groups).  Same LDS bytes, same MFMA cycles per FLOP as one 32x32x16 per fragment, but the chip holds a ~15 % higher
+clock on this shape under the kernel's load (tools/dev/ubench/shape_ubench.hip: 1.92-1.96 vs 1.66-1.69 GHz, 11 %
+less wall time per chunk; MI355X_MICROARCH.md 'DVFS give-back' item 7).
+
+Data layout (shared with k_pack_mlp and the kernel prologue, point_mfma.hip):
+  * lane l: c = l & 15 (column), g = l >> 4 (k-quarter).  The wave's points are (cg, c), cg = 0, 1.
+  * X^T (512 features x 32 points, fp32) = 32 row groups x 2 column groups of 16x16 accumulators,
+    X(rg, cg) = a[8 rg + 4 cg : +3]; lane (g, c) register r holds feature 16 rg + 4 g + r of point (cg, c).
+    (The C++ side still sees 16 'tiles' of 16 registers, tile t = a[16t : 16t+15] = row groups 2t, 2t+1.)
+  * a weight fragment = the A operand of one MFMA pair: 16 rows x 32 k, lane (row = l & 15, g) holds k = 8 g + j.
+  * B operands built from accumulators (relu(x), relu(h)): element j of lane group g in a 32-wide k-step is row
+    (j < 4 ? 4 g + j : 16 + 4 g + j - 4) of that k-step — the packer stores fc_0 / fc_1 / lin_out with the same permutation.
+  * a stage = 16 fragments (16 KiB) of the packed stream; a k-step of an x-stage = 2 stages (row groups 0-15, 16-31).
+
+Contract with k_point_mfma:
+  * x tiles pinned: operands %0..%15 "+{a[16t:16t+15]}"; %16-%20 loader/consumer cursor in/out (st_slot, ld_idx,
+    ld_slot, ld_rep, ld_wrap); then per block the inputs listed at each generator function.
+  * entry: the next stage to consume is published, DMA of the two stages after it is in flight; exit: all LDS reads
+    drained, accumulators readable, cursor advanced.
+Registers used inside (all declared clobbered): v10-13 slot read bases, v14 address temp, v15 DMA lane offset, v16-23 B pair of the
+x-stages, v40-55 / v72-87 the two chunk accumulators (VGPR-form MFMA), v44-51 next B pair (x-stages), v60-67 relu(h)
+fragments, v68-71 temps, v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 k-steps x 2 column groups x 4),
+s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
 """
 import os
-import sys
-
+import re
 
 DIAG = os.environ.get("PNR_ASM_DIAG", "")      # timing experiments only: 'nobarrier', 'nodma', 'nowait' (results are garbage)
 
@@ -30,26 +43,86 @@ def A(i):
     return f"v[{96 + 4 * i}:{99 + 4 * i}]"
 
 
-def XB(t, s):
-    b = 128 + (t * 2 + s) * 4
+def XB(ks, cg):
+    b = 128 + (ks * 2 + cg) * 4
     return f"v[{b}:{b + 3}]"
 
 
-def gen(dt):
-    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
-    cvt = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[dt]
-    L = []
-    e = L.append
+def X(rg, cg):
+    b = 8 * rg + 4 * cg
+    return f"a[{b}:{b + 3}]"
 
-    def relu_pack(dst, a0, a1, tmp):
-        e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
-        e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
-        e(f"{cvt} v{dst}, v{tmp}, v{tmp + 1}")
-        e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
-        if dt == "f16":
-            e(f"v_pk_min_i16 v{dst}, v{dst}, s38")          # saturate +inf/NaN to 65504
 
-    def loader_advance():
+def HB(cg):
+    return f"v[{60 + 4 * cg}:{63 + 4 * cg}]"
+
+
+def BX(cg):
+    return f"v[{16 + 4 * cg}:{19 + 4 * cg}]"
+
+
+class Emit:
+    """Instruction list + a scoreboard of the outstanding LDS reads (they return in order), so every s_waitcnt
+    lgkmcnt(N) is computed from the program order instead of counted by hand."""
+
+    def __init__(self, dt):
+        self.dt = dt
+        self.mfma = {"bf16": "v_mfma_f32_16x16x32_bf16", "f16": "v_mfma_f32_16x16x32_f16"}[dt]
+        self.cvt = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[dt]
+        self.L = []
+        self.reads = []          # tags of outstanding LDS reads, oldest first
+        self.loop_state = []
+
+    def e(self, line):
+        self.L.append(line)
+
+    def ds_read(self, tag, text):
+        self.L.append(text)
+        self.reads.append(tag)
+        assert len(self.reads) <= 15, ("more than 15 LDS reads in flight", self.reads)
+
+    def need(self, tags):
+        idx = max([i for i, t in enumerate(self.reads) if t in tags], default=-1)
+        if idx < 0:
+            return
+        self.e(f"s_waitcnt lgkmcnt({len(self.reads) - 1 - idx})")
+        self.reads = self.reads[idx + 1:]
+
+    def drain(self):
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.reads = []
+
+    def loop_begin(self, label):
+        self.loop_state.append(list(self.reads))
+        self.e(f"{label}:")
+
+    def loop_end(self):
+        st = self.loop_state.pop()
+        assert st == self.reads, ("LDS scoreboard differs between loop entry and back edge", st, self.reads)
+
+    def relu_pack(self, dst, a0, a1, tmp):
+        self.e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
+        self.e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
+        self.relu_pack_v(dst, tmp, tmp + 1)
+
+    def relu_pack_v(self, dst, v0, v1):
+        self.e(f"{self.cvt} v{dst}, v{v0}, v{v1}")
+        if "cvtnop" in DIAG:
+            self.e("s_nop 1")
+        self.e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
+        if self.dt == "f16":
+            self.e(f"v_pk_min_i16 v{dst}, v{dst}, s38")          # saturate +inf/NaN to 65504
+
+    def snapshot_ks(self, ks):
+        """relu(x) of row groups 2ks, 2ks+1 -> the two B fragments of k-step ks (16 accumulator reads, 8 packs)."""
+        for cg in range(2):
+            for half in range(2):            # half 0: row group 2ks (elements 0-3), half 1: row group 2ks+1 (elements 4-7)
+                base = 8 * (2 * ks + half) + 4 * cg
+                for p in range(2):
+                    self.relu_pack(128 + (ks * 2 + cg) * 4 + 2 * half + p, base + 2 * p, base + 2 * p + 1, 68 + 2 * p)
+
+    def loader_advance(self):
+        e = self.e
         e("s_add_u32 s21, s21, 1")
         e("s_add_u32 s24, s24, 0x4000")
         e("s_addc_u32 s25, s25, 0")
@@ -65,26 +138,55 @@ def gen(dt):
         e("s_cselect_b32 s29, s27, s26")
         e("2:")
 
-    def dma(f, k):
-        if f % 4 != 1:
-            return
-        q = f >> 2
-        if q == 0:
-            e(f"s_mov_b32 m0, s{40 + k}")
-            e("s_nop 0")
-        e(f"global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-        if q == 3:
-            loader_advance()
-
-    def begin_stage():
+    def stage(self, mm, rd_cur, rd_nxt, m0_sreg, hooks=None):
+        """One stage: 16 fragments, fragment f in A(f & 7).  mm(f) -> the two MFMA lines of fragment f.  rd_cur / rd_nxt:
+        VGPRs holding this lane's read base of this stage's / the next stage's ring slot; m0_sreg: SGPR with the LDS-DMA
+        destination of the stage being loaded meanwhile.  The refill of A(f & 7) (fragment f + 8) is issued one MFMA late
+        (after the first MFMA of fragment f + 1) and the 4 DMA pieces after the second MFMA of fragments 1, 5, 9, 13, so
+        no MFMA gap carries more than one of them.  hooks: {f: callable} extra work after fragment f's second MFMA."""
+        e = self.e
         e("s_waitcnt vmcnt(4)")
         e("s_barrier")
+        pend = None
+        for f in range(16):
+            if f % 4 == 0:
+                self.need([f"A{(f + i) & 7}" for i in range(4)])
+            m1, m2 = mm(f)
+            e(m1)
+            if pend:
+                self.ds_read(*pend)
+            e(m2)
+            if f % 4 == 1:
+                q = f >> 2
+                if q == 0:
+                    e(f"s_mov_b32 m0, {m0_sreg}")
+                    e("s_nop 0")
+                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                if q == 3:
+                    self.loader_advance()
+            base = rd_cur if f < 8 else rd_nxt
+            pend = (f"A{f & 7}", f"ds_read_b128 {A(f & 7)}, {base} offset:{((f + 8) & 15) * 1024}")
+            if hooks and f in hooks:
+                hooks[f]()
+        self.ds_read(*pend)
 
-    def refill(f, k):
-        base = 10 + k if f < 8 else 10 + ((k + 1) & 3)
-        e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
+    def read_first_frags(self, base):
+        for i in range(8):
+            self.ds_read(f"A{i}", f"ds_read_b128 {A(i)}, {base} offset:{i * 1024}")
 
-    # ---------------------------------------------------------------- setup
+
+def setup_cursor(E, cfg, stream):
+    e = E.e
+    # hipcc may have a scalar (kernel-argument) load or an LDS access of its own in flight when the statement starts: both
+    # count in lgkmcnt, SMEM returns out of order, and every wait below is a COUNTED lgkmcnt(N) — drain them first
+    e("s_waitcnt lgkmcnt(0)")
+    # ... and start with no LDS-DMA piece of the previous statement in flight.  Measured (tools/dev/dbg_prec6.py, fp16 build,
+    # 3 .. 250 workgroups): without this wait a statement that OPENS with x-stages while the previous statement's last two
+    # stages of pieces are still landing returns run-to-run different results (30 dB); vmcnt(0) here, or a 256-cycle
+    # s_sleep, makes them exact and repeatable, while vmcnt(4), a barrier, vmcnt(0) / lgkmcnt(0) at every stage INSIDE the
+    # statements, or a drain behind the x-stages do not.  It costs 0.1 % (the pieces are two stages old).  The mechanism is
+    # not identified; DESIGN.md §8 lists what was ruled out.
+    e("s_waitcnt vmcnt(0)")
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
     e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
@@ -93,197 +195,55 @@ def gen(dt):
     e("s_mov_b32 s22, %18")
     e("s_mov_b32 s23, %19")
     e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %21, 0xfff")
-    e("s_bfe_u32 s27, %21, 0xc000c")                         # offset 12, width 12
-    e("s_bfe_u32 s28, %21, 0x80018")                         # offset 24, width 8
-    e("s_mov_b64 s[36:37], %22")
+    e(f"s_and_b32 s26, {cfg}, 0xfff")
+    e(f"s_bfe_u32 s27, {cfg}, 0xc000c")                      # offset 12, width 12
+    e(f"s_bfe_u32 s28, {cfg}, 0x80018")                      # offset 24, width 8
+    e(f"s_mov_b64 s[36:37], {stream}")
     e("s_lshl_b32 s35, s21, 14")
     e("s_add_u32 s24, s36, s35")
     e("s_addc_u32 s25, s37, 0")
-    if dt == "f16":
+    if E.dt == "f16":
         e("s_mov_b32 s38, 0x7bff7bff")
-    # optional prefix (%29 != 0): the block's lin_z stages 'x += M . B' + lin_z.bias, B image at %28 — one asm entry/exit
-    # and one pipeline refill less per block than a separate x-stages call
-    e("s_cmp_eq_u32 %29, 0")
-    e("s_cbranch_scc1 5f")
-    xstages_core(e, mfma, "%28", "%29")
-    e("5:")
-    for k in range(4):                                       # stage k of a chunk uses slot (st_slot+1+k)&3; the bias stage = k 3
-        e(f"s_add_u32 s35, s20, {1 + k}")
-        e("s_and_b32 s35, s35, 3")
-        e("s_lshl_b32 s35, s35, 14")
-        e(f"v_add_u32 v{10 + k}, s35, %24")
-        e(f"s_add_u32 s35, s22, {1 + k}")
-        e("s_and_b32 s35, s35, 3")
-        e("s_lshl_b32 s35, s35, 14")
-        e(f"s_add_u32 s{40 + k}, s35, %23")
-    e("v_mov_b32 v14, %26")
-    e("v_mov_b32 v15, %25")
-    e("v_mov_b32 v16, %27")
-    e("v_mov_b32 v17, 0")
-    e("v_mov_b32 v18, 0")
-    e("v_mov_b32 v19, 0")
-    # chunk 0's fc_0.bias rows into the chunk accumulator, then the first 8 fragments of the bias stage
-    for q in range(4):
-        e(f"ds_read_b128 v[{40 + 4 * q}:{43 + 4 * q}], v14 offset:{32 * q}")
-    e("v_add_u32 v14, 0x80, v14")
-    for i in range(8):
-        e(f"ds_read_b128 {A(i)}, v13 offset:{i * 1024}")
 
-    # ---------------------------------------------------------------- snapshot interleaved with the fc_1-bias stage
-    begin_stage()
-    for t in range(16):
-        for s in range(2):
-            for p in range(4):
-                relu_pack(128 + (t * 2 + s) * 4 + p, 16 * t + 8 * s + 2 * p, 16 * t + 8 * s + 2 * p + 1, 68 + 2 * (p & 1))
-        f = t
-        if f % 4 == 0:
-            e("s_waitcnt lgkmcnt(4)")
-        e(f"{mfma} a[{16 * t}:{16 * t + 15}], {A(f & 7)}, v[16:19], a[{16 * t}:{16 * t + 15}]")
-        refill(f, 3)
-        dma(f, 3)
 
-    # ---------------------------------------------------------------- 16 chunks, software-pipelined
-    # Stage order of a block (the packer follows it, k_pack_mlp): bias | F(0) | F(1) G(0) | F(2) G(1) | ... | F(15) G(14) | G(15)
-    # with F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[c] . relu(x)) and G(c) = its 2 fc_1 stages
-    # (x += W1[:, c] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
-    # other — finished 32 MFMAs earlier — is converted to relu(h_c) in the MFMA gaps and reloaded with the fc_0.bias
-    # rows of chunk c+2, so no MFMA waits for a conversion and no s_nop pads the chain's tail.
-    # Stage index i within the block (bias stage = 0) consumes ring slot (st_slot + i) & 3: refill/dma position k = (i-1) & 3.
-    ACC = (40, 72)
-
-    def fc0_stage(acc, i, half, hook=None, first_wait=4):
-        k = (i - 1) & 3
-        begin_stage()
-        for f in range(16):
-            if f % 4 == 0:
-                e(f"s_waitcnt lgkmcnt({first_wait if f == 0 else 4})")
-            e(f"{mfma} v[{acc}:{acc + 15}], {A(f & 7)}, {XB(8 * half + (f >> 1), f & 1)}, v[{acc}:{acc + 15}]")
-            refill(f, k)
-            dma(f, k)
-            if hook:
-                hook(f)
-
-    def fc1_stage(i, half, first_wait=4):
-        k = (i - 1) & 3
-        begin_stage()
-        for f in range(16):
-            tn = 8 * half + (f >> 1)
-            if f % 4 == 0:
-                e(f"s_waitcnt lgkmcnt({first_wait if f == 0 else 4})")
-            e(f"{mfma} a[{16 * tn}:{16 * tn + 15}], {A(f & 7)}, v[{60 + 4 * (f & 1)}:{63 + 4 * (f & 1)}], a[{16 * tn}:{16 * tn + 15}]")
-            refill(f, k)
-            dma(f, k)
-
-    def convert_hook(acc, reload):
-        """relu(h) of the finished accumulator -> v60-67, one register per MFMA gap (gaps 2..9); then (gap 15) the next
-        fc_0.bias rows into it.  The 4 bias loads are younger than that stage's refills: the next stage's first wait
-        allows 8 outstanding."""
-        def hook(f):
-            if 2 <= f <= 9:
-                i = f - 2
-                e(f"{cvt} v{60 + i}, v{acc + 2 * i}, v{acc + 2 * i + 1}")
-                e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
-                if dt == "f16":
-                    e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
-            if f == 15 and reload:
-                for q in range(4):
-                    e(f"ds_read_b128 v[{acc + 4 * q}:{acc + 4 * q + 3}], v14 offset:{32 * q}")
-                e("v_add_u32 v14, 0x80, v14")
-        return hook
-
-    def body(c_parity, i0, reload=True):
-        """F(c+1) into ACC[1-c_parity] with the conversion of ACC[c_parity] riding in its first stage, then G(c)."""
-        fc0_stage(ACC[1 - c_parity], i0, 0, hook=convert_hook(ACC[c_parity], reload))
-        fc0_stage(ACC[1 - c_parity], i0 + 1, 1, first_wait=8 if reload else 4)
-        fc1_stage(i0 + 2, 0)
-        fc1_stage(i0 + 3, 1)
-
-    # chunk 1's fc_0.bias rows into the second accumulator (chunk 0's went into v40-55 in the setup)
-    for q in range(4):
-        e(f"ds_read_b128 v[{72 + 4 * q}:{75 + 4 * q}], v14 offset:{32 * q}")
-    e("v_add_u32 v14, 0x80, v14")
-    fc0_stage(ACC[0], 1, 0, first_wait=8)                     # F(0): stage indices 1, 2 (the 4 loads above are younger than its fragments)
-    fc0_stage(ACC[0], 2, 1)
-    e("s_mov_b32 s34, 7")
-    e("1:")
-    body(0, 3)                                               # c even:  F(c+1) on v72.., h_c from v40..
-    body(1, 3)                                               # c odd :  F(c+1) on v40.., h_c from v72..  (stage positions repeat mod 4)
-    e("s_sub_u32 s34, s34, 1")
-    e("s_cmp_lg_u32 s34, 0")
-    e("s_cbranch_scc1 1b")
-    body(0, 3, reload=False)                                 # c = 14: F(15) on v72.., no chunk 16 to preload
-    # G(15): convert v72.. (its chain's last MFMA is 32 MFMAs back), then the last two fc_1 stages
-    begin_stage()
-    for i in range(8):
-        e(f"{cvt} v{60 + i}, v{72 + 2 * i}, v{73 + 2 * i}")
-        e(f"v_pk_max_i16 v{60 + i}, v{60 + i}, 0")
-        if dt == "f16":
-            e(f"v_pk_min_i16 v{60 + i}, v{60 + i}, s38")
-    k = (63 - 1) & 3
-    for f in range(16):
-        tn = f >> 1
-        if f % 4 == 0:
-            e("s_waitcnt lgkmcnt(4)")
-        e(f"{mfma} a[{16 * tn}:{16 * tn + 15}], {A(f & 7)}, v[{60 + 4 * (f & 1)}:{63 + 4 * (f & 1)}], a[{16 * tn}:{16 * tn + 15}]")
-        refill(f, k)
-        dma(f, k)
-    fc1_stage(64, 1)
-
-    # ---------------------------------------------------------------- exit
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 15")
-    e("s_nop 15")
+def exit_cursor(E, advance):
+    """advance = stages consumed by the fixed part since s20/s22 were last normalised."""
+    e = E.e
     e("s_mov_b32 m0, s39")
-    e("s_add_u32 s20, s20, 1")
+    e(f"s_add_u32 s20, s20, {advance}")
     e("s_and_b32 %16, s20, 3")
     e("s_mov_b32 %17, s21")
-    e("s_add_u32 s22, s22, 1")
+    e(f"s_add_u32 s22, s22, {advance}")
     e("s_and_b32 %18, s22, 3")
     e("s_mov_b32 %19, s23")
     e("s_mov_b32 %20, s29")
-    return L
 
 
-def xstages_core(e, mfma, baddr, cfg2):
-    """The stage loop of gen_xstages, entered with the cursor in s20-s29/s[24:25]/s[36:37]: n_lds = cfg2 & 0xff stages
-    with B from the LDS image at `baddr` (+1024 per stage), then (cfg2 bit 8) one bias stage with B = (%27,0,0,0).
-    Leaves s20 (st_slot) and s22 (ld_slot) advanced and masked; uses v10, v11, v14-v19, v44-v47, s34, s35, s40."""
+def fixed_bases(E, ring_lane, ring_wave):
+    """Stage i of the fixed part reads ring slot (s20 + i) & 3 through v[10 + (i & 3)]; while it runs, the stage three
+    ahead is loaded into slot (s22 + i) & 3, DMA destination s[40 + (i & 3)]."""
+    e = E.e
+    for k in range(4):
+        e(f"s_add_u32 s35, s20, {k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"v_add_u32 v{10 + k}, s35, {ring_lane}")
+        e(f"s_add_u32 s35, s22, {k}")
+        e("s_and_b32 s35, s35, 3")
+        e("s_lshl_b32 s35, s35, 14")
+        e(f"s_add_u32 s{40 + k}, s35, {ring_wave}")
 
-    def loader_advance():
-        e("s_add_u32 s21, s21, 1")
-        e("s_add_u32 s24, s24, 0x4000")
-        e("s_addc_u32 s25, s25, 0")
-        e("s_cmp_lg_u32 s21, s29")
-        e("s_cbranch_scc1 2f")
-        e("s_mov_b32 s21, 0")
-        e("s_mov_b64 s[24:25], s[36:37]")
-        e("s_add_u32 s23, s23, 1")
-        e("s_cmp_lg_u32 s23, s28")
-        e("s_cselect_b32 s23, s23, 0")
-        e("s_sub_u32 s35, s28, 1")
-        e("s_cmp_eq_u32 s23, s35")
-        e("s_cselect_b32 s29, s27, s26")
-        e("2:")
 
-    def stage_body(breg):
-        # cur base v10, nxt base v11, M0 value s40, B fragment in v[breg:breg+3]
-        e("s_waitcnt vmcnt(4)")
-        e("s_barrier")
-        for f in range(16):
-            if f % 4 == 0:
-                e("s_waitcnt lgkmcnt(4)")
-            e(f"{mfma} a[{16 * f}:{16 * f + 15}], {A(f & 7)}, v[{breg}:{breg + 3}], a[{16 * f}:{16 * f + 15}]")
-            base = 10 if f < 8 else 11
-            e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
-            if f % 4 == 1:
-                q = f >> 2
-                if q == 0:
-                    e("s_mov_b32 m0, s40")
-                    e("s_nop 0")
-                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-                if q == 3:
-                    loader_advance()
+def fixed_stage(E, i, mm, hooks=None):
+    E.stage(mm, f"v{10 + (i & 3)}", f"v{10 + ((i + 1) & 3)}", f"s{40 + (i & 3)}", hooks)
+
+
+def xstages_core(E, baddr, cfg2, ring_lane, ring_wave, dma_off, bias_dword, allow_init=False):
+    """cfg2 & 0xff k-steps 'x += W . B' with B = the k-step image at LDS address `baddr` ([k-step][column group][lane] x 16 B,
+    2 KiB per k-step), then (cfg2 bit 8) one bias k-step with B = (bias_dword, 0, 0, 0).  A k-step = 2 stages (row groups
+    0-15, 16-31).  Enters with the cursor in s20-s29 / s[24:25] / s[36:37]; leaves s20 (st_slot) and s22 (ld_slot) advanced
+    and masked, all LDS reads drained except the first 8 fragments of the next stage (in A, tags A0-A7)."""
+    e = E.e
 
     def advance_slots():
         e("s_add_u32 s20, s20, 1")
@@ -294,199 +254,282 @@ def xstages_core(e, mfma, baddr, cfg2):
         e("s_add_u32 s35, s20, 1")
         e("s_and_b32 s35, s35, 3")
         e("s_lshl_b32 s35, s35, 14")
-        e("v_add_u32 v11, s35, %24")                          # nxt
+        e(f"v_add_u32 v11, s35, {ring_lane}")                # nxt
         e("s_lshl_b32 s35, s22, 14")
-        e("s_add_u32 s40, s35, %23")                          # DMA destination of the stage being loaded
+        e(f"s_add_u32 s40, s35, {ring_wave}")                # DMA destination of the stage being loaded
 
-    e(f"s_and_b32 s34, {cfg2}, 0xff")                         # n_lds
+    def mm_half(half, init=False):
+        def mm(f):
+            rg = 16 * half + f
+            return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {BX(cg)}, " + ("0" if init else X(rg, cg)) for cg in range(2)]
+        return mm
+
+    def kstep_body(init=False):
+        E.stage(mm_half(0, init), "v10", "v11", "s40")
+        advance_slots()
+        E.stage(mm_half(1, init), "v10", "v11", "s40")
+        advance_slots()
+
+    def next_b_and_kstep(init):
+        E.ds_read("N0", "ds_read_b128 v[44:47], v14")        # next k-step's B pair (the one past the last is never used)
+        E.ds_read("N1", "ds_read_b128 v[48:51], v14 offset:1024")
+        e("v_add_u32 v14, 0x800, v14")
+        kstep_body(init)
+        E.need(["N0", "N1"])
+        e("s_nop 7")                                         # the last MFMAs have read the old B
+        for i in range(8):
+            e(f"v_mov_b32 v{16 + i}, v{44 + i}")
+
+    e(f"s_and_b32 s34, {cfg2}, 0xff")                        # k-steps with B from the LDS image
     e("s_lshl_b32 s35, s20, 14")
-    e("v_add_u32 v10, s35, %24")                              # cur
+    e(f"v_add_u32 v10, s35, {ring_lane}")                    # cur
     e("s_add_u32 s35, s20, 1")
     e("s_and_b32 s35, s35, 3")
     e("s_lshl_b32 s35, s35, 14")
-    e("v_add_u32 v11, s35, %24")                              # nxt
+    e(f"v_add_u32 v11, s35, {ring_lane}")                    # nxt
     e("s_lshl_b32 s35, s22, 14")
-    e("s_add_u32 s40, s35, %23")
+    e(f"s_add_u32 s40, s35, {ring_wave}")
     e(f"v_mov_b32 v14, {baddr}")
-    e("v_mov_b32 v15, %25")
-    e("ds_read_b128 v[16:19], v14")                           # B of the first k-step
-    e("v_add_u32 v14, 0x400, v14")
-    for i in range(8):
-        e(f"ds_read_b128 {A(i)}, v10 offset:{i * 1024}")
+    e(f"v_mov_b32 v15, {dma_off}")
+    E.ds_read("B0", "ds_read_b128 v[16:19], v14")            # B pair of the first k-step
+    E.ds_read("B1", "ds_read_b128 v[20:23], v14 offset:1024")
+    e("v_add_u32 v14, 0x800, v14")
+    E.read_first_frags("v10")
+    E.need(["B0", "B1"])
+    if allow_init:
+        # cfg2 bit 9: the first k-step WRITES x (C = 0) instead of accumulating — LIN_IN starts the residual stream, so the
+        # caller neither zeroes 256 accumulators nor keeps them live into this statement
+        e(f"s_bitcmp1_b32 {cfg2}, 9")
+        e("s_cbranch_scc0 6f")
+        saved = list(E.reads)
+        next_b_and_kstep(True)
+        assert saved == E.reads
+        e("s_sub_u32 s34, s34, 1")
+        e("6:")
     e("s_cmp_eq_u32 s34, 0")
     e("s_cbranch_scc1 3f")
-    e("1:")
-    e("ds_read_b128 v[44:47], v14")                           # next k-step's B (the one past the last is never used)
-    e("v_add_u32 v14, 0x400, v14")
-    stage_body(16)
-    advance_slots()
-    e("s_waitcnt lgkmcnt(8)")                                 # next B landed (8 younger fragment reads may be in flight)
-    e("s_nop 7")                                              # the stage's last MFMAs have read the old B
-    e("v_mov_b32 v16, v44")
-    e("v_mov_b32 v17, v45")
-    e("v_mov_b32 v18, v46")
-    e("v_mov_b32 v19, v47")
+    E.loop_begin("1")
+    next_b_and_kstep(False)
     e("s_sub_u32 s34, s34, 1")
     e("s_cmp_lg_u32 s34, 0")
     e("s_cbranch_scc1 1b")
+    E.loop_end()
     e("3:")
-    e(f"s_bitcmp1_b32 {cfg2}, 8")                             # bias stage requested?
+    e(f"s_bitcmp1_b32 {cfg2}, 8")                            # bias k-step requested?
     e("s_cbranch_scc0 4f")
-    e("v_mov_b32 v16, %27")
-    e("v_mov_b32 v17, 0")
-    e("v_mov_b32 v18, 0")
-    e("v_mov_b32 v19, 0")
+    e(f"v_mov_b32 v16, {bias_dword}")
+    for i in range(1, 8):
+        e(f"v_mov_b32 v{16 + i}, 0")
+    e("v_mov_b32 v20, v16")
     e("s_nop 1")
-    stage_body(16)
-    advance_slots()
+    saved = list(E.reads)
+    kstep_body()
+    assert saved == E.reads
     e("4:")
 
 
 def gen_xstages(dt):
-    """n_lds stages 'x[tn] += A_tn . B' with B = the k-step image [k][lane] at LDS address %26 (+1024 per stage, 16 k-steps
-    per 256-channel group -> the caller passes the address of the first k-step), then (cfg2 bit 8) one bias stage.
-    Operands: %0-%15 x tiles, %16-%20 cursor in/out (as the resblock), %21 cfg, %22 stream, %23 ring+wave*4096 (s),
-    %24 ring+lane*16 (v), %25 DMA lane offset (v), %26 B image address (v), %27 bias B dword 0 (v), %28 cfg2 = n_lds | bias<<8."""
-    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
-    L = []
-    e = L.append
+    """Operands: %0-%15 x tiles, %16-%20 cursor in/out, %21 cfg = P1 | (P1+P2)<<12 | NS<<24 (the loader's view of the stream),
+    %22 stream base (s64), %23 ring LDS base + wave*4096 (s), %24 ring LDS base + lane*16 (v), %25 DMA lane offset
+    wave*4096 + lane*16 (v), %26 B image address + lane*16 (v), %27 bias B dword 0 (v), %28 cfg2 = k-steps | bias<<8 | init<<9
+    (init: the first k-step overwrites x; the caller then passes the tiles as outputs only)."""
+    E = Emit(dt)
+    setup_cursor(E, "%21", "%22")
+    xstages_core(E, "%26", "%28", "%24", "%23", "%25", "%27", allow_init=True)
+    E.drain()
+    E.e("s_nop 15")
+    E.e("s_nop 15")
+    E.e("s_mov_b32 m0, s39")
+    E.e("s_mov_b32 %16, s20")
+    E.e("s_mov_b32 %17, s21")
+    E.e("s_mov_b32 %18, s22")
+    E.e("s_mov_b32 %19, s23")
+    E.e("s_mov_b32 %20, s29")
+    return E.L
+
+
+def bias_kstep_with_snapshot(E, i0, first_hooks=None):
+    """The block's bias k-step as stages i0, i0+1 of the fixed part (B = v16-23 = bias pair): the second stage carries the
+    snapshot relu(x) -> XB of row groups 0-15 (k-steps 0-7), whose bias MFMAs ran a stage earlier.  Row groups 16-31 are
+    converted by the caller inside the next stage (snapshot_hooks(8))."""
+    def mm_half(half):
+        def mm(f):
+            rg = 16 * half + f
+            return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {BX(cg)}, {X(rg, cg)}" for cg in range(2)]
+        return mm
+    fixed_stage(E, i0, mm_half(0), first_hooks)
+    fixed_stage(E, i0 + 1, mm_half(1), snapshot_hooks(E, 0))
+
+
+def snapshot_hooks(E, ks0):
+    """k-steps ks0 .. ks0+7, one per two fragments (fragments 0, 2, .., 14)."""
+    return {2 * i: (lambda ks=ks0 + i: E.snapshot_ks(ks)) for i in range(8)}
+
+
+def gen(dt):
+    """One resblock.  Inputs after the common %0-%20: %21 cfg, %22 stream (s64), %23 ring + wave*4096 (s), %24 ring +
+    lane*16 (v), %25 DMA lane offset (v), %26 LDS address of fc_0.bias[block] + 16*(lane>>4) (v), %27 bias B dword 0 (v),
+    %28 lin_z B image address + lane*16 (v), %29 lin_z cfg2 = k-steps (0 = none; the bias k-step is always part of the block).
+    Stage order (k_pack_mlp follows it): [lin_z k-steps x 2] | bias x 2 | F(0) | F(1) G(0) | ... | F(15) G(14) | G(15), with
+    F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[32c..32c+31, :] . relu(x)) and G(c) = its 2 fc_1 stages
+    (x += W1[:, 32c..32c+31] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
+    other — finished 64 MFMAs earlier — is converted to relu(h_c) in the MFMA gaps and reloaded with the fc_0.bias rows of
+    chunk c+2."""
+    E = Emit(dt)
+    e = E.e
+    setup_cursor(E, "%21", "%22")
+    if "drainA" in DIAG:
+        e("s_waitcnt vmcnt(0)")
+    if "waitA4" in DIAG:
+        e("s_waitcnt vmcnt(4)")
+    if "sleepA" in DIAG:
+        e("s_sleep 4")
+    if "barA" in DIAG:
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+    e("s_cmp_eq_u32 %29, 0")
+    e("s_cbranch_scc1 5f")
+    xstages_core(E, "%28", "%29", "%24", "%23", "%25", "%27")
+    E.drain()                                                # both paths reach 5: with nothing in flight
+    e("5:")
+    if "drainB" in DIAG:
+        e("s_waitcnt vmcnt(0)")
+    fixed_bases(E, "%24", "%23")
+    e("v_mov_b32 v14, %26")
+    e("v_mov_b32 v15, %25")
+    e("v_mov_b32 v16, %27")
+    for i in range(1, 8):
+        e(f"v_mov_b32 v{16 + i}, 0")
+    e("v_mov_b32 v20, v16")
+    ACC = (40, 72)
+
+    def hbias(acc, tagp):
+        """fc_0.bias rows of the next chunk into a chunk accumulator: register r of (rgl, cg) = bias[32 c + 16 rgl + 4 g + r]."""
+        for rgl in range(2):
+            for cg in range(2):
+                b = acc + 8 * rgl + 4 * cg
+                E.ds_read(f"{tagp}{rgl}{cg}", f"ds_read_b128 v[{b}:{b + 3}], v14 offset:{64 * rgl}")
+        e("v_add_u32 v14, 0x80, v14")
+
+    hbias(ACC[0], "h")                                       # chunk 0
+    E.read_first_frags("v10")
+    # ---------------------------------------------------------------- bias k-step + snapshot
+    bias_kstep_with_snapshot(E, 0)
+
+    def mm_fc0(acc, half):
+        def mm(f):
+            rgl, ks = f & 1, 8 * half + (f >> 1)
+            return [f"{E.mfma} v[{acc + 8 * rgl + 4 * cg}:{acc + 8 * rgl + 4 * cg + 3}], {A(f & 7)}, {XB(ks, cg)}, "
+                    f"v[{acc + 8 * rgl + 4 * cg}:{acc + 8 * rgl + 4 * cg + 3}]" for cg in range(2)]
+        return mm
+
+    def mm_fc1(half):
+        def mm(f):
+            rg = 16 * half + f
+            return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {HB(cg)}, {X(rg, cg)}" for cg in range(2)]
+        return mm
+
+    def convert_hooks(acc, reload):
+        """relu(h) of the finished accumulator -> v60-67 (hb[cg] dword 2 rgl + p), one register per fragment (fragments
+        2..9); then (fragment 15) the next fc_0.bias rows into it."""
+        hooks = {}
+        for i in range(8):
+            cg, rgl, p = i >> 2, (i >> 1) & 1, i & 1
+            src = acc + 8 * rgl + 4 * cg + 2 * p
+            hooks[2 + i] = (lambda d=60 + 4 * cg + 2 * rgl + p, s=src: E.relu_pack_v(d, s, s + 1))
+        if reload:
+            hooks[15] = lambda: hbias(acc, "h")
+        return hooks
+
+    def F(acc, i, hooks0=None, need_bias=True):
+        if need_bias:
+            E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
+        fixed_stage(E, i, mm_fc0(acc, 0), hooks0)
+        fixed_stage(E, i + 1, mm_fc0(acc, 1))
+
+    def G(i):
+        fixed_stage(E, i, mm_fc1(0))
+        fixed_stage(E, i + 1, mm_fc1(1))
+
+    # chunk 1's fc_0.bias rows into the second accumulator, then F(0) with the snapshot of k-steps 8-15 in its first stage
+    hbias(ACC[1], "g")
+    E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
+    F(ACC[0], 2, snapshot_hooks(E, 8), need_bias=False)
+    # the loop head: outstanding = [g-bias reads?]  make the state explicit: the g reads are waited for here
+    E.need([f"g{rgl}{cg}" for rgl in range(2) for cg in range(2)])
+    if "drainC" in DIAG:
+        e("s_waitcnt vmcnt(0)")
+    e("s_mov_b32 s34, 7")
+    E.loop_begin("1")
+    # c even: F(c+1) on v72.., h_c from v40.. (its conversion + the preload of chunk c+2 ride in F's first stage)
+    F(ACC[1], 4, convert_hooks(ACC[0], True), need_bias=False)
+    G(6)
+    E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
+    # c odd: F(c+1) on v40.., h_c from v72..
+    F(ACC[0], 8, convert_hooks(ACC[1], True), need_bias=False)
+    G(10)
+    E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
+    e("s_sub_u32 s34, s34, 1")
+    e("s_cmp_lg_u32 s34, 0")
+    e("s_cbranch_scc1 1b")
+    E.loop_end()
+    # c = 14: F(15) on v72.., no chunk 16 to preload; G(14); then G(15) from v72..
+    F(ACC[1], 60, convert_hooks(ACC[0], False), need_bias=False)
+    G(62)
+    # G(15): its accumulator's last MFMA is 64 MFMAs back — convert, then the two fc_1 stages
+    for i in range(8):
+        cg, rgl, p = i >> 2, (i >> 1) & 1, i & 1
+        src = ACC[1] + 8 * rgl + 4 * cg + 2 * p
+        E.relu_pack_v(60 + 4 * cg + 2 * rgl + p, src, src + 1)
+    G(64)
+    # ---------------------------------------------------------------- exit: 2 bias + 64 chunk stages consumed
+    E.drain()
     e("s_nop 15")
     e("s_nop 15")
-    e("s_mov_b32 s39, m0")
-    e("s_mov_b32 s20, %16")
-    e("s_mov_b32 s21, %17")
-    e("s_mov_b32 s22, %18")
-    e("s_mov_b32 s23, %19")
-    e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %21, 0xfff")
-    e("s_bfe_u32 s27, %21, 0xc000c")
-    e("s_bfe_u32 s28, %21, 0x80018")
-    e("s_mov_b64 s[36:37], %22")
-    e("s_lshl_b32 s35, s21, 14")
-    e("s_add_u32 s24, s36, s35")
-    e("s_addc_u32 s25, s37, 0")
-    xstages_core(e, mfma, "%26", "%28")
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 15")
-    e("s_nop 15")
-    e("s_mov_b32 m0, s39")
-    e("s_mov_b32 %16, s20")
-    e("s_mov_b32 %17, s21")
-    e("s_mov_b32 %18, s22")
-    e("s_mov_b32 %19, s23")
-    e("s_mov_b32 %20, s29")
-    return L
+    exit_cursor(E, 66)
+    return E.L
 
 
 def gen_linout(dt):
-    """lin_out(relu(x)): the snapshot of tile t (relu + 16-bit pack of a[16t:16t+15]) is emitted right before the two MFMAs
-    that consume it, so the conversion VALU work hides the chain's MFMAs; 2 stages, one accumulator (v40-55, rows 0..3 of
-    the output tile are valid), returned in %21-%24 (the caller adds lin_out.bias and applies sigmoid / relu).
-    Operands: %0-%15 x tiles, %16-%20 cursor in/out, %21-%24 out (=&v), %25 cfg, %26 stream, %27 ring+wave*4096 (s),
-    %28 ring+lane*16 (v), %29 DMA lane offset (v)."""
-    mfma = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[dt]
-    cvt = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[dt]
-    L = []
-    e = L.append
-
-    def loader_advance():
-        e("s_add_u32 s21, s21, 1")
-        e("s_add_u32 s24, s24, 0x4000")
-        e("s_addc_u32 s25, s25, 0")
-        e("s_cmp_lg_u32 s21, s29")
-        e("s_cbranch_scc1 2f")
-        e("s_mov_b32 s21, 0")
-        e("s_mov_b64 s[24:25], s[36:37]")
-        e("s_add_u32 s23, s23, 1")
-        e("s_cmp_lg_u32 s23, s28")
-        e("s_cselect_b32 s23, s23, 0")
-        e("s_sub_u32 s35, s28, 1")
-        e("s_cmp_eq_u32 s23, s35")
-        e("s_cselect_b32 s29, s27, s26")
-        e("2:")
-
-    def relu_pack(dst, a0, a1, tmp):
-        e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
-        e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
-        e(f"{cvt} v{dst}, v{tmp}, v{tmp + 1}")
-        e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
-        if dt == "f16":
-            e(f"v_pk_min_i16 v{dst}, v{dst}, s38")
-
-    e("s_nop 15")
-    e("s_nop 15")
-    e("s_mov_b32 s39, m0")
-    e("s_mov_b32 s20, %16")
-    e("s_mov_b32 s21, %17")
-    e("s_mov_b32 s22, %18")
-    e("s_mov_b32 s23, %19")
-    e("s_mov_b32 s29, %20")
-    e("s_and_b32 s26, %25, 0xfff")
-    e("s_bfe_u32 s27, %25, 0xc000c")
-    e("s_bfe_u32 s28, %25, 0x80018")
-    e("s_mov_b64 s[36:37], %26")
-    e("s_lshl_b32 s35, s21, 14")
-    e("s_add_u32 s24, s36, s35")
-    e("s_addc_u32 s25, s37, 0")
-    if dt == "f16":
-        e("s_mov_b32 s38, 0x7bff7bff")
-    for k in range(3):                                       # read bases of stage 0, stage 1 and the stage after (read-ahead only)
-        e(f"s_add_u32 s35, s20, {k}")
-        e("s_and_b32 s35, s35, 3")
-        e("s_lshl_b32 s35, s35, 14")
-        e(f"v_add_u32 v{10 + k}, s35, %28")
-    for k in range(2):                                       # DMA destinations of the two stages loaded meanwhile
-        e(f"s_add_u32 s35, s22, {k}")
-        e("s_and_b32 s35, s35, 3")
-        e("s_lshl_b32 s35, s35, 14")
-        e(f"s_add_u32 s{40 + k}, s35, %27")
-    e("v_mov_b32 v15, %29")
-    for i in range(16):
-        e(f"v_mov_b32 v{40 + i}, 0")
+    """The last fc_1.bias k-step, then lin_out(relu(x)): 1 stage of 16 fragments (k-steps 0-15, rows 0-3 of each valid), into
+    v40-47 (column group cg -> v[40+4cg : 43+4cg], rows 0-3 = registers 0-3 of lanes 0-15).  The 8 results are written to the
+    wave's LDS buffer at %26 ([cg][lane] x 16 B) for the caller (lin_out.bias + sigmoid / relu happen there).
+    Operands: %0-%15 x tiles, %16-%20 cursor, %21 cfg, %22 stream, %23 ring+wave*4096 (s), %24 ring+lane*16 (v), %25 DMA lane
+    offset (v), %26 result address + lane*16 (v), %27 bias B dword 0 (v)."""
+    E = Emit(dt)
+    e = E.e
+    setup_cursor(E, "%21", "%22")
+    fixed_bases(E, "%24", "%23")
+    e("v_mov_b32 v15, %25")
+    e("v_mov_b32 v16, %27")
+    for i in range(1, 8):
+        e(f"v_mov_b32 v{16 + i}, 0")
+    e("v_mov_b32 v20, v16")
     for i in range(8):
-        e(f"ds_read_b128 {A(i)}, v10 offset:{i * 1024}")
-    for half in range(2):
-        e("s_waitcnt vmcnt(4)")
-        e("s_barrier")
-        for f in range(16):
-            t = 8 * half + (f >> 1)
-            if f % 2 == 0:
-                for sidx in range(2):
-                    for pidx in range(4):
-                        relu_pack(128 + (t * 2 + sidx) * 4 + pidx, 16 * t + 8 * sidx + 2 * pidx, 16 * t + 8 * sidx + 2 * pidx + 1, 68 + 2 * (pidx & 1))
-            if f % 4 == 0:
-                e("s_waitcnt lgkmcnt(4)")
-            e(f"{mfma} v[40:55], {A(f & 7)}, {XB(t, f & 1)}, v[40:55]")
-            base = 10 + half if f < 8 else 11 + half
-            e(f"ds_read_b128 {A(f & 7)}, v{base} offset:{((f + 8) & 15) * 1024}")
-            if f % 4 == 1:
-                q = f >> 2
-                if q == 0:
-                    e(f"s_mov_b32 m0, s{40 + half}")
-                    e("s_nop 0")
-                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-                if q == 3:
-                    loader_advance()
+        e(f"v_mov_b32 v{40 + i}, 0")
+    E.read_first_frags("v10")
+    bias_kstep_with_snapshot(E, 0)
+
+    def mm(f):
+        return [f"{E.mfma} v[{40 + 4 * cg}:{43 + 4 * cg}], {A(f & 7)}, {XB(f, cg)}, v[{40 + 4 * cg}:{43 + 4 * cg}]" for cg in range(2)]
+    # k-steps 8-15 are converted while k-steps 0-7 are multiplied: k-step 8+i is complete after fragment i, used at fragment 8+i
+    hooks = {i: (lambda ks=8 + i: E.snapshot_ks(ks)) for i in range(8)}
+    fixed_stage(E, 2, mm, hooks)
+    E.drain()
+    e("s_nop 15")
+    e("s_nop 15")
+    e("ds_write_b128 %26, v[40:43]")
+    e("ds_write_b128 %26, v[44:47] offset:1024")
     e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 15")
-    e("s_nop 15")
-    e("s_nop 15")
-    for i in range(4):
-        e(f"v_mov_b32 %{21 + i}, v{40 + i}")
-    e("s_mov_b32 m0, s39")
-    e("s_add_u32 s20, s20, 2")
-    e("s_and_b32 %16, s20, 3")
-    e("s_mov_b32 %17, s21")
-    e("s_add_u32 s22, s22, 2")
-    e("s_and_b32 %18, s22, 3")
-    e("s_mov_b32 %19, s23")
-    e("s_mov_b32 %20, s29")
-    return L
+    exit_cursor(E, 3)
+    return E.L
 
 
 def gen_viewspill():
-    """Park this view's residual stream: x (16 tiles) -> workspace slot, float4 index (t*4+q)*64 + lane.
-    Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v)."""
+    """Park this view's residual stream: the 256 accumulator registers -> workspace slot, float4 index (t*4+q)*64 + lane
+    (layout-agnostic: the reduce reads the same registers back).  Operands: %0-%15 x tiles (pinned), %16 slot base (s64),
+    %17 lane*16 (v).  Hazards covered inside: MFMA write -> VMEM read of the AGPR (entry s_nop), store data -> overwrite of
+    the source AGPRs (vmcnt(0) before the statement ends)."""
     L = []
     e = L.append
     e("s_nop 15")
@@ -497,8 +540,6 @@ def gen_viewspill():
             e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
         e("s_add_u32 s24, s24, 0x1000")
         e("s_addc_u32 s25, s25, 0")
-    # The stores source their data straight from the accumulator tiles: have them retired before anything may overwrite
-    # a tile (measured: without this wait a build whose compiler-side code happened not to wait here read back wrong tiles).
     e("s_waitcnt vmcnt(0)")
     return L
 
@@ -517,8 +558,6 @@ def gen_viewreduce():
         e("s_addc_u32 s25, s25, 0")
 
     def combine_pass(op):
-        # The parked streams sit in L2 / Infinity Cache: nine tiles (36 x 1 KiB loads per wave) are kept in flight ahead of
-        # the tile being combined.
         NB, D = 10, 9
         buf = lambda t: 96 + 16 * (t % NB)
         for t in range(D):
@@ -581,6 +620,14 @@ def main():
                 lines = [l for l in lines if l != "s_barrier"]
             if "nowait" in DIAG:
                 lines = [("s_nop 0" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
+            if "fullwait" in DIAG or "drain" in DIAG:
+                pass
+            if "nosat" in DIAG:
+                lines = [l for l in lines if not l.startswith("v_pk_min_i16")]
+            if "fullwait" in DIAG:
+                lines = [("s_waitcnt vmcnt(0)" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
+            if "ldswait" in DIAG:
+                lines = [("s_waitcnt lgkmcnt(0)" if l.startswith("s_waitcnt lgkmcnt(") else l) for l in lines]
             if "nodma" in DIAG:
                 lines = [l for l in lines if not l.startswith("global_load_lds")]
                 lines = [("s_nop 0" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
@@ -588,11 +635,10 @@ def main():
             for l in lines:
                 f.write(f'    "{l}\\n\\t" \\\n')
             f.write('    ""\n\n')
-        clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 20)) + list(range(40, 56)) + list(range(60, 88)) + list(range(96, 256))] \
+        clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 24)) + list(range(40, 56)) + list(range(60, 88)) + list(range(96, 256))] \
             + [f"s{i}" for i in list(range(20, 32)) + list(range(33, 44))]
         f.write("#define PNR_RESBLOCK_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
     # audit: every physical v/s register the text names must be declared clobbered (operands are %N references)
-    import re
     body = open(out).read()
     body = body[:body.index("#define PNR_RESBLOCK_CLOBBERS")]
     used = {m.group(1) + m.group(2) for m in re.finditer(r"\b([vs])(\d+)\b", body)}
