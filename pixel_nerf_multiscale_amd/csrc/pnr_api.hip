@@ -9,7 +9,8 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
 // point_mfma.hip
 uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
-                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s,
+                   const RayJob* job = nullptr);
 // train_f32.hip
 uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
@@ -220,6 +221,30 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     uint64_t pws_bytes = workspace_bytes - (uint64_t)((char*)pws - (char*)workspace);
     const pnr_noise nz = noise ? *noise : pnr_noise{nullptr, nullptr, nullptr, nullptr};
 
+    if (Kf > 0 && (!outputs->fine_rgb || !outputs->fine_depth)) return PNR_E_NULL;
+
+    if (params->precision != PNR_F32) {
+        // The MFMA kernel renders a pass in ONE launch: coarse positions generated in the tile prologue, the network, and the
+        // compositing of every finished ray by the workgroup that evaluated it (point_mfma.hip).  Between the passes one small
+        // launch resamples (a 256-element sort per ray has no place between two MFMA tiles).
+        RayJob job{};
+        job.on = 1; job.K = Kc; job.gen_z = 1; job.lindisp = params->lindisp; job.white_bkgd = params->white_bkgd;
+        job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.ray_base = ray_index_base;
+        job.z_out = zc; job.w_out = w_c; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        PointSrc src{rays, nullptr, Kc, nullptr, nullptr};
+        if (outputs->ev_point_begin) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_begin, s));
+        if ((rc = point_mfma(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s, &job))) return rc;
+        if (outputs->ev_point_end) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_end, s));
+        if (Kf == 0) return PNR_OK;
+        if ((rc = pnr_sample_fine(rays, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
+                                  nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream))) return rc;
+        job.K = Kt; job.gen_z = 0; job.noise_c = nullptr; job.z_out = nullptr;
+        job.w_out = outputs->fine_weights; job.rgb_out = outputs->fine_rgb; job.depth_out = outputs->fine_depth;
+        PointSrc srcf{rays, zf, Kt, nullptr, nullptr};
+        return point_mfma(params, fine ? fine : coarse, views, srcf, n_rays * Kt, rays_per_obj * Kt, rgbs, pws, pws_bytes, s, &job);
+    }
+
+    // fp32 path: the stages as separate launches
     // coarse pass (nerf.py:273-282)
     if ((rc = pnr_sample_coarse(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, ray_index_base, zc, stream))) return rc;
     PointSrc src{rays, zc, Kc, nullptr, nullptr};
@@ -230,7 +255,6 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     if (Kf == 0) return PNR_OK;
 
     // fine pass (nerf.py:284-301); mlp_fine=None falls back to the coarse MLP (backup2:258)
-    if (!outputs->fine_rgb || !outputs->fine_depth) return PNR_E_NULL;
     if ((rc = pnr_sample_fine(rays, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
                               nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream))) return rc;
     PointSrc srcf{rays, zf, Kt, nullptr, nullptr};

@@ -79,6 +79,25 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
     }
     return v;
 }
+// The same reductions with the lane index handed in (bit-identical results: same exchanges, same order).  The fused render
+// launch passes a lane index the optimiser cannot trace to the hardware lane id, so the six permute addresses are formed where
+// they are used instead of being hoisted to the kernel's entry and kept (spilled) across the MFMA blocks.
+__device__ __forceinline__ float shfl_at(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ float wave_sum_l(float v, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_at(v, lane ^ o);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul_l(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = shfl_at(v, lane >= o ? lane - o : lane);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
 
 // ---------------------------------------------------------------- cameras / projection
 // One source view after PixelNeRFNet.encode (models.py.backup2:121-150).
@@ -179,6 +198,154 @@ __device__ __forceinline__ float posenc_elem(const float* x, int d, int j, float
     float ph = (q & 1) ? 1.57079637050628662109375f : 0.0f;   // fp32(pi/2), as the reference buffer holds it
     return sinf(fmaf(x[i], f, ph));              // addcmul(phase, x, freq)
 }
+
+// ---------------------------------------------------------------- per-ray stages as device functions
+// (shared by the stage kernels of stage_kernels.hip and by the fused render launch of point_mfma.hip)
+// sample_coarse (nerf.py:98-118): z = near(1-t)+far*t  (or 1/((1-t)/near + t/far)),  t = linspace(0,1-1/Kc,Kc)[k] + U*(1/Kc)
+__device__ __forceinline__ float z_from_t(float t, float near, float far, int lindisp) {
+    if (!lindisp) return near * (1.0f - t) + far * t;
+    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+}
+__device__ __forceinline__ float linspace_k(int k, int n) {
+    // torch.linspace(0, 1-step, n): start + k*(end-start)/(n-1), mirrored from the end in the upper half
+    float step = 1.0f / (float)n;
+    float end = 1.0f - step;
+    if (n == 1) return 0.0f;
+    float inc = end / (float)(n - 1);
+    return (k < n / 2) ? inc * (float)k : end - inc * (float)(n - 1 - k);
+}
+
+// gen_rays (util.py:118-148,243-281): pinhole camera looking down -z, pixel -> world ray
+struct RayCam { float R[9]; float o[3]; float fx, fy, cx, cy, zn, zf; int W, H; };
+__device__ __forceinline__ void pinhole_ray(const RayCam& c, int pix, float* d) {
+    float y = (float)(pix / c.W), x = (float)(pix % c.W);
+    float X = (x - c.cx) / c.fx, Y = (y - c.cy) / c.fy;
+    float v[3] = {X, -Y, -1.0f};
+    float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] /= nrm; v[1] /= nrm; v[2] /= nrm;
+    rot3(c.R, v, d);
+}
+
+// Loads that another wave of the SAME workgroup may have just stored (the fused launch composites what its own waves wrote a
+// moment ago; a 128-byte line can hold samples of a ray composited earlier, whose stale copy would still sit in the CU's L1):
+// NT = true bypasses the L1 (MI355X_MICROARCH.md, visibility table: nt / sc1 loads are L2-served).
+template <bool NT> __device__ __forceinline__ float ld_f(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ float4 ld_f4(const float4* p) {
+    if (!NT) return *p;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v v = __builtin_nontemporal_load((const f4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// composite (nerf.py:178-182,223-249), one WAVE per ray: alpha = 1-exp(-delta*relu(sigma)); T = exclusive
+// cumprod(1-alpha+1e-10); w = alpha*T; rgb = sum w c (+ 1 - sum w if white background); depth = sum w z.  The transmittance
+// product is a wave-wide multiplicative scan per 64-sample segment with a carry.  Returns (rgb, depth) in lane 0.
+template <bool NT>
+__device__ __forceinline__ float4 composite_ray(const float* zr, const float4* cr, int K, float far, int white_bkgd,
+                                                float* wr /* or null */, int lane) {
+    float carry = 1.0f;
+    float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, aw = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        int k = k0 + lane;
+        bool act = k < K;
+        float zk = act ? ld_f<NT>(zr + k) : 0.f;
+        float zn = (k + 1 < K) ? ld_f<NT>(zr + k + 1) : far;   // delta_K = far - z_K
+        float4 c = act ? ld_f4<NT>(cr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float delta = zn - zk;
+        float alpha = act ? 1.0f - expf(-delta * fmaxf(c.w, 0.0f)) : 0.0f;
+        float tr = act ? (1.0f - alpha) + 1e-10f : 1.0f;
+        float incl = wave_scan_mul_l(tr, lane);
+        float excl = shfl_at(incl, lane > 0 ? lane - 1 : 0);
+        if (lane == 0) excl = 1.0f;
+        float w = alpha * (carry * excl);
+        carry *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+        if (act && wr) wr[k] = w;
+        ar += w * c.x; ag += w * c.y; ab += w * c.z; ad += w * zk; aw += w;
+    }
+    ar = wave_sum_l(ar, lane); ag = wave_sum_l(ag, lane); ab = wave_sum_l(ab, lane); ad = wave_sum_l(ad, lane);
+    aw = wave_sum_l(aw, lane);
+    if (white_bkgd) { float bg = 1.0f - aw; ar = ar + bg; ag = ag + bg; ab = ab + bg; }
+    return make_float4(ar, ag, ab, ad);
+}
+
+// sample_fine + sample_fine_depth + cat + sort (nerf.py:120-161,285-295), one WAVE per ray with wave-private LDS scratch
+// `cdf` (Kc+2 floats) and `buf` (P2 = pow2 >= Kc+n_imp+n_dep floats):
+//   cdf[0..Kc]  = [0, cumsum((w+1e-5)/sum(w+1e-5))]
+//   importance: i = #(cdf <= u) - 1 clamped at 0 (NO upper clamp), t = (i + r)/Kc -> z
+//   depth:      z = clamp(depth + g*depth_std, near, far)
+//   merged with z_coarse and sorted ascending (bitonic network, +inf padding).
+// SYNC() orders the wave's LDS accesses between the phases (__syncthreads in the stage kernel; a wave-level fence in the fused one).
+struct FineArgs { int Kc, n_imp, n_dep, P2, lindisp; float depth_std; const float* un; const float* rn; const float* gn; uint64_t seed; };
+template <bool NT, typename Sync>
+__device__ __forceinline__ void sample_fine_ray(const FineArgs& f, const float* zc /* this ray */, const float* w /* this ray */,
+                                                float depth, float near, float far, int64_t ray_local, int64_t ray_global,
+                                                bool live, float* cdf, float* buf, float* z_out /* this ray */, int lane,
+                                                Sync sync) {
+    const int Kc = f.Kc, n_imp = f.n_imp, n_dep = f.n_dep, P2 = f.P2, Kt = Kc + n_imp + n_dep;
+    float carry = 0.f;
+    if (live && n_imp > 0) {
+        float s = 0.f;
+        for (int k = lane; k < Kc; k += 64) s += ld_f<NT>(w + k) + 1e-5f;
+        s = wave_sum(s);
+        if (lane == 0) cdf[0] = 0.f;
+        for (int k0 = 0; k0 < Kc; k0 += 64) {
+            int k = k0 + lane;
+            float p = (k < Kc) ? (ld_f<NT>(w + k) + 1e-5f) / s : 0.f;
+            float inc = wave_scan_add(p, lane) + carry;
+            if (k < Kc) cdf[k + 1] = inc;
+            carry = __shfl(inc, 63, 64);
+        }
+    }
+    for (int k = lane; k < P2; k += 64) buf[k] = (live && k < Kc) ? ld_f<NT>(zc + k) : __builtin_inff();
+    sync();
+    if (live) {
+        for (int j = lane; j < n_imp; j += 64) {
+            float u = f.un ? f.un[ray_local * n_imp + j] : rng_uniform(f.seed, ray_global, DRAW_U, j);
+            float r = f.rn ? f.rn[ray_local * n_imp + j] : rng_uniform(f.seed, ray_global, DRAW_R, j);
+            int cnt = 0;
+            for (int k = 0; k <= Kc; ++k) cnt += (cdf[k] <= u) ? 1 : 0;     // searchsorted(right=True)
+            float ind = fmaxf((float)cnt - 1.0f, 0.0f);
+            float t = (ind + r) / (float)Kc;
+            buf[Kc + j] = z_from_t(t, near, far, f.lindisp);
+        }
+        for (int j = lane; j < n_dep; j += 64) {
+            float g = f.gn ? f.gn[ray_local * n_dep + j] : rng_normal(f.seed, ray_global, DRAW_G, j);
+            float zz = depth + g * f.depth_std;
+            buf[Kc + n_imp + j] = fmaxf(fminf(zz, far), near);
+        }
+    }
+    sync();
+    for (int sz = 2; sz <= P2; sz <<= 1) {
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = lane; i < (P2 >> 1); i += 64) {
+                int lo = ((i / st) * (st << 1)) + (i % st);
+                int hi = lo + st;
+                bool asc = ((lo & sz) == 0);
+                float a = buf[lo], b = buf[hi];
+                bool sw = asc ? (a > b) : (a < b);
+                if (sw) { buf[lo] = b; buf[hi] = a; }
+            }
+            sync();
+        }
+    }
+    if (live)
+        for (int k = lane; k < Kt; k += 64) z_out[k] = buf[k];
+}
+
+// The per-ray work a point launch of the MFMA kernel also does (the fused render launch of pnr_render, point_mfma.hip):
+// workgroups own whole rays; sample positions are generated and the finished rays composited inside the launch.
+struct RayJob {
+    int on;                         // 0: plain point launch (pnr_point_mlp)
+    int K;                          // samples per ray of this pass
+    int gen_z;                      // 1: coarse positions generated in the kernel (and written to z_out); 0: PointSrc.z
+    int lindisp, white_bkgd;
+    int from_cam;                   // 1: ray r is pixel pix0 + r of `cam` (no ray tensor)
+    int rays_per_wg;
+    int64_t n_rays;
+    const float* noise_c; uint64_t seed; int64_t ray_base;
+    float* z_out; float* w_out; float* rgb_out; float* depth_out;      // w_out may be NULL
+    RayCam cam; int pix0;
+};
 
 // Where a point comes from (see pnr_point_mlp in pnr.h).
 struct PointSrc {

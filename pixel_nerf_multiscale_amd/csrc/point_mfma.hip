@@ -281,6 +281,8 @@ struct MfmaArgs {
     int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
     int use_code_viewdirs, num_freqs;
     float freq_factor;
+    int tiles_per_wg;              // plain launch: workgroup b owns tiles [b tiles_per_wg, (b+1) tiles_per_wg)
+    RayJob job;                    // fused render launch: workgroup b owns rays [b rays_per_wg, ...) (see pnr_common.h)
 };
 
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
@@ -313,6 +315,19 @@ __device__ __forceinline__ void glds_gather_ray(const float* pr, const char* pz_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
                  "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "v"(pz_m1024), "s"(lds_dst) : "memory");
+}
+// the two halves of glds_gather_ray on their own (positions generated in the kernel / rays generated from a camera)
+__device__ __forceinline__ void glds_gather_ray_only(const float* pr, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_gather_z_only(const char* pz_m1024, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off offset:1024\n\t"
+                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pz_m1024), "s"(lds_dst) : "memory");
 }
 // Explicit points: lane l moves the three components of its 12-byte record to dst + 256 k + 4 l (p = &record[0]).
 __device__ __forceinline__ void glds_gather_xyz(const char* p, uint32_t lds_dst) {
@@ -363,7 +378,35 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     int ld_idx = 0, ld_rep = 0, ld_slot = 0, st_slot = 0;
     int ld_wrap = (a.ldNS == 1) ? a.ldP1 + a.P2 : a.ldP1;
     const uint32_t ring_lds = lds_addr(smem + LDS_RING) + wv * 4096;
-    const bool small_idx = a.n_points < 0x7fffffffLL;
+    // 64-bit divisions are ~100 instructions each on this machine: point counts below 2^31 take a 32-bit path.  The divisor
+    // goes through an opaque copy so that its reciprocal is formed at the use, not kept from the kernel's entry in scratch.
+    auto div_pts = [&](int64_t num, int64_t den) __attribute__((always_inline)) -> int64_t {
+        if (a.n_points < 0x7fffffffLL) {
+            uint32_t d32 = (uint32_t)den;
+            asm volatile("" : "+s"(d32));
+            return (int64_t)((uint32_t)num / d32);
+        }
+        return num / den;
+    };
+    // ---------------- this workgroup's points [p_begin, p_end): whole rays in a fused render launch (so that a ray is composited
+    // by the workgroup that evaluated it), whole tiles otherwise.  The host keeps p_end - p_begin below 2^31.
+    const bool ray_mode = a.src.rays != nullptr || a.job.from_cam;
+    int64_t p_begin, p_end, ray_begin = 0;
+    if (a.job.on) {
+        ray_begin = (int64_t)blockIdx.x * a.job.rays_per_wg;
+        ray_begin = ray_begin < a.job.n_rays ? ray_begin : a.job.n_rays;
+        int64_t ray_end = ray_begin + a.job.rays_per_wg;
+        ray_end = ray_end < a.job.n_rays ? ray_end : a.job.n_rays;
+        p_begin = ray_begin * a.job.K;
+        p_end = ray_end * a.job.K;
+    } else {
+        p_begin = (int64_t)blockIdx.x * a.tiles_per_wg * TILE_PTS;
+        p_begin = p_begin < a.n_points ? p_begin : a.n_points;
+        p_end = p_begin + (int64_t)a.tiles_per_wg * TILE_PTS;
+        p_end = p_end < a.n_points ? p_end : a.n_points;
+    }
+    const int n_loc = (int)(p_end - p_begin);
+    const int my_tiles = (n_loc + TILE_PTS - 1) / TILE_PTS;
     // ---------------- point inputs of a tile -> this wave's LDS buffer `buf` (0/1), by LDS-DMA with per-lane sources.
     // rays mode: [half][point][16 B] = (o, d.x | d.yz, near, far) at 0 / 512, z at 1024 + 4 point; explicit points: component k
     // of xyz at 256 k + 4 point, of dirs at 256 k + 128 + 4 point.  Point pl = lane & 31 of the wave; indices clamped to the last point.
@@ -371,17 +414,23 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     auto prefetch_points = [&](int tile, int buf) __attribute__((always_inline)) {
         const int lane = lane_id();
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(pts_wave) + buf * PTS_BYTES);
-        int64_t gp = (int64_t)tile * TILE_PTS + wv * 32 + (lane & 31);
-        gp = gp < a.n_points ? gp : a.n_points - 1;
-        if (a.src.rays) {
-            // 64-bit divisions are ~100 instructions each on this machine: point counts below 2^31 take the 32-bit path
-            const int64_t ray = small_idx ? (int64_t)((uint32_t)gp / (uint32_t)a.src.K) : gp / a.src.K;
+        int lp = tile * TILE_PTS + wv * 32 + (lane & 31);            // index within the workgroup's range
+        lp = lp < n_loc ? lp : n_loc - 1;
+        const int64_t gp = p_begin + lp;
+        if (a.job.on) {
+            int Kq = a.job.K;
+            asm volatile("" : "+s"(Kq));
+            const int64_t ray = ray_begin + (uint32_t)lp / (uint32_t)Kq;
+            if (!a.job.from_cam) glds_gather_ray_only(a.src.rays + ray * 8 + (lane >> 5) * 4, dst);
+            if (!a.job.gen_z) glds_gather_z_only((const char*)(a.src.z + gp) - 1024, dst);
+        } else if (a.src.rays) {
+            const int64_t ray = div_pts(gp, a.src.K);
             glds_gather_ray(a.src.rays + ray * 8 + (lane >> 5) * 4, (const char*)(a.src.z + gp) - 1024, dst);
         } else {
             glds_gather_xyz((const char*)((lane < 32 ? a.src.xyz : a.src.dirs) + gp * 3), dst);     // 12-byte records
         }
     };
-    if ((int)blockIdx.x < a.n_tiles) prefetch_points(blockIdx.x, 0);
+    if (my_tiles > 0) prefetch_points(0, 0);
     {
         const uint32_t gl_off = (uint32_t)(wv * 4096 + lane_id() * 16);
         const char* dma_g = a.stream;                               // global base of the stage being loaded (uniform)
@@ -448,23 +497,41 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     const int p_steps = a.proj ? a.SZ - 8 * a.Gg : 0;     // texel k-steps of the projected last level
     // the last lin_z call of a block (a gathered group, or the projected part) runs as the prefix of the resblock asm
     const int n_groups = a.proj ? n_gather : n_gather - 1;  // gathered groups that go through separate x_stages calls
+    // ---------------- compositing of this workgroup's finished rays (fused render launch): ray lr of the workgroup by wave
+    // lr & 3, from what the waves stored to `out` (and z_out) — through the L2: see ld_f in pnr_common.h
+    auto composite_rays = [&](int lr0, int lr1) __attribute__((always_inline)) {
+        const int lane = lane_id();
+        const int K = a.job.K;
+        for (int lr = lr0 + ((wv - lr0) & 3); lr < lr1; lr += 4) {
+            const int64_t ray = ray_begin + lr;
+            const float far = a.job.from_cam ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
+            const float* zr = (a.job.gen_z ? a.job.z_out : a.src.z) + ray * K;
+            const float4 r = composite_ray<true>(zr, (const float4*)a.out + ray * K, K, far, a.job.white_bkgd,
+                                                 a.job.w_out ? a.job.w_out + ray * K : nullptr, lane);
+            if (lane == 0) {
+                a.job.rgb_out[ray * 3 + 0] = r.x; a.job.rgb_out[ray * 3 + 1] = r.y; a.job.rgb_out[ray * 3 + 2] = r.z;
+                a.job.depth_out[ray] = r.w;
+            }
+        }
+    };
+    int rays_done = 0;     // rays of the workgroup composited so far
     int pbuf = 0;
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, pbuf ^= 1) {
+    for (int tile = 0; tile < my_tiles; ++tile, pbuf ^= 1) {
         STAMP(st_t);
 #ifdef PNR_STAMPS
         st_tile = st_t;
 #endif
         // this tile's point inputs landed a tile ago (or before the ring prologue's wait); fetch the next tile's now
-        if (tile + (int)gridDim.x < a.n_tiles) prefetch_points(tile + gridDim.x, pbuf ^ 1);
+        if (tile + 1 < my_tiles) prefetch_points(tile + 1, pbuf ^ 1);
         const char* pts = pts_wave + pbuf * PTS_BYTES;
         // lane (g, c) serves points (cg, c), cg = 0, 1: tile-local index wv*32 + 16 cg + c.  Source-view index of such a point
         // for view pass v (one object: v itself, wave-uniform):
         auto view_of = [&](int cc, int cg, int vv) __attribute__((always_inline)) -> int {
             if (a.vw.n_objs == 1) return vv;
-            int64_t gi = (int64_t)tile * TILE_PTS + wv * 32 + 16 * cg + cc;
-            gi = gi < a.n_points ? gi : a.n_points - 1;
-            // 64-bit divisions are ~100 instructions each on this machine: point counts below 2^31 take the 32-bit path
-            const int ob = small_idx ? (int)((uint32_t)gi / (uint32_t)a.pts_per_obj) : (int)(gi / a.pts_per_obj);
+            int li = tile * TILE_PTS + wv * 32 + 16 * cg + cc;
+            li = li < n_loc ? li : n_loc - 1;
+            const int64_t gi = p_begin + li;
+            const int ob = (int)div_pts(gi, a.pts_per_obj);
             return ob * a.NS + vv;
         };
         int v = 0;      // current source-view pass
@@ -592,11 +659,41 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     const Cam cam = a.vw.n_objs == 1 ? load_cam(a.vw, __builtin_amdgcn_readfirstlane(v)) : load_cam(a.vw, view_of(c, cg, v));
                     float p[3], d[3], xr[3], dr[3];
                     const int pl = 16 * cg + c;
-                    if (a.src.rays) {
-                        const float4 r0 = *(const float4*)(pts + pl * 16), r1 = *(const float4*)(pts + 512 + pl * 16);
-                        const float zz = *(const float*)(pts + 1024 + pl * 4);
-                        d[0] = r0.w; d[1] = r1.x; d[2] = r1.y;
-                        p[0] = r0.x + zz * d[0]; p[1] = r0.y + zz * d[1]; p[2] = r0.z + zz * d[2];
+                    if (ray_mode) {
+                        float o3[3], near, far, zz;
+                        int li = tile * TILE_PTS + wv * 32 + pl;
+                        const bool in_range = li < n_loc;
+                        li = in_range ? li : n_loc - 1;
+                        // divisors opaque to the optimiser: their reciprocals would otherwise be formed once at the kernel's
+                        // entry and kept across the MFMA blocks in scratch (see lane_id above)
+                        int Kq = a.job.K;
+                        asm volatile("" : "+s"(Kq));
+                        const int lr = a.job.on ? (int)((uint32_t)li / (uint32_t)Kq) : 0;     // ray within the workgroup
+                        if (a.job.from_cam) {
+                            RayCam cam_q = a.job.cam;
+                            asm volatile("" : "+s"(cam_q.W), "+s"(cam_q.fx), "+s"(cam_q.fy));
+                            pinhole_ray(cam_q, a.job.pix0 + (int)ray_begin + lr, d);
+                            o3[0] = cam_q.o[0]; o3[1] = cam_q.o[1]; o3[2] = cam_q.o[2];
+                            near = cam_q.zn; far = cam_q.zf;
+                        } else {
+                            const float4 r0 = *(const float4*)(pts + pl * 16), r1 = *(const float4*)(pts + 512 + pl * 16);
+                            o3[0] = r0.x; o3[1] = r0.y; o3[2] = r0.z;
+                            d[0] = r0.w; d[1] = r1.x; d[2] = r1.y; near = r1.z; far = r1.w;
+                        }
+                        if (a.job.gen_z) {
+                            // sample_coarse (nerf.py:98-118), the arithmetic of k_sample_coarse; view pass 0 leaves the positions
+                            // in z_out for the compositing, the fine resampling and the caller
+                            const int k = li - lr * Kq;
+                            const int64_t gp = p_begin + li;
+                            const float u = a.job.noise_c ? a.job.noise_c[gp]
+                                                          : rng_uniform(a.job.seed, a.job.ray_base + ray_begin + lr, DRAW_COARSE, k);
+                            const float t = linspace_k(k, Kq) + u * (1.0f / (float)Kq);
+                            zz = z_from_t(t, near, far, a.job.lindisp);
+                            if (v == 0 && g == 0 && in_range) a.job.z_out[gp] = zz;
+                        } else {
+                            zz = *(const float*)(pts + 1024 + pl * 4);
+                        }
+                        p[0] = o3[0] + zz * d[0]; p[1] = o3[1] + zz * d[1]; p[2] = o3[2] + zz * d[2];
                     } else {
                         const float* q3 = (const float*)(pts + pl * 4);
                         p[0] = q3[0]; p[1] = q3[64]; p[2] = q3[128];
@@ -641,6 +738,14 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 uvw[lane] = make_float4(pu[0], pv[0], pu[1], pv[1]);      // for the gather / tap image of this view's blocks
                 STAMP_ACC(1, st_t);
                 lin_in_stages();
+                if (a.job.on && v == 0 && tile > 0) {
+                    // the rays the previous tile finished: every wave has been through the vmcnt(0) and the barriers of the
+                    // LIN_IN statement since it stored that tile's outputs, so they are in the L2 for any wave to read
+                    int upto = tile * TILE_PTS;
+                    upto = __builtin_amdgcn_readfirstlane((int)((uint32_t)(upto < n_loc ? upto : n_loc) / (uint32_t)a.job.K));
+                    composite_rays(rays_done, upto);
+                    rays_done = upto;
+                }
                 if (a.proj && n_gather == 0) tap_image();          // fully projected: the image serves all blocks of this view
                 else if (!a.proj && n_gather == 1) gather(0);
                 STAMP_ACC(2, st_t);
@@ -710,8 +815,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             // the block left rows 0..3 of the output in the wave's LDS buffer: [column group][lane (g = 0: lanes 0..15)] x float4.
             // Lanes 0..31 store the wave's 32 consecutive points.
             const int lane = lane_id();
-            const int64_t gi = (int64_t)tile * TILE_PTS + wv * 32 + lane;
-            if (lane < 32 && gi < a.n_points) {
+            const int li = tile * TILE_PTS + wv * 32 + lane;
+            const int64_t gi = p_begin + li;
+            if (lane < 32 && li < n_loc) {
                 const float4 o = *(const float4*)(zwave + (lane >> 4) * 1024 + (lane & 15) * 16);
                 const float* bo = btab + a.n_blocks * HID;
                 float4 res;
@@ -726,6 +832,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #ifdef PNR_STAMPS
         st_acc[0] += st_t - st_tile;
 #endif
+    }
+    if (a.job.on) {
+        // the rays the last tile finished
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        composite_rays(rays_done, n_loc / a.job.K);
     }
 #ifdef PNR_STAMPS
     if (lane_id() == 0) {
@@ -759,7 +872,7 @@ uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
 }
 
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
-                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
+                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s, const RayJob* job) {
     Layout y;
     const int proj = mlp->packed_texels;
     const int last = vw->n_levels - 1;
@@ -799,7 +912,26 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.use_code_viewdirs = prm->use_code_viewdirs; a.num_freqs = prm->num_freqs; a.freq_factor = prm->freq_factor;
     int grid = num_cus();
     if (grid > MAX_GRID) grid = MAX_GRID;
-    if (grid > a.n_tiles) grid = a.n_tiles;
+    a.job = RayJob{};
+    a.tiles_per_wg = 0;
+    if (job && job->on) {
+        // whole rays per workgroup, at least about a tile's worth of points each
+        a.job = *job;
+        if (a.job.K < 1 || a.job.n_rays * a.job.K != n_points || !a.job.rgb_out || !a.job.depth_out) return PNR_E_SHAPE;
+        if (a.job.gen_z ? !a.job.z_out : !src.z) return PNR_E_NULL;
+        if (!a.job.from_cam && !src.rays) return PNR_E_NULL;
+        int64_t rpw = (a.job.n_rays + grid - 1) / grid;
+        const int64_t min_rpw = (TILE_PTS + a.job.K - 1) / a.job.K;
+        if (rpw < min_rpw) rpw = min_rpw;
+        if (rpw * a.job.K >= 0x7fffffffLL) return PNR_E_SHAPE;
+        a.job.rays_per_wg = (int)rpw;
+        grid = (int)((a.job.n_rays + rpw - 1) / rpw);
+    } else {
+        int64_t tpw = ((int64_t)a.n_tiles + grid - 1) / grid;
+        if (tpw * TILE_PTS >= 0x7fffffffLL) return PNR_E_SHAPE;
+        a.tiles_per_wg = (int)tpw;
+        grid = (int)((a.n_tiles + tpw - 1) / tpw);
+    }
     const size_t lds = LDS_BTAB + (size_t)y.btab_floats * 4;
     const void* fn;
     const bool mv = a.NS > 1;

@@ -5,22 +5,7 @@
 
 namespace pnr {
 
-// ------------------------------------------------------------------ sample_coarse  (nerf.py:98-118)
-// z[i,k] = near(1-t)+far*t  (or 1/((1-t)/near + t/far)),  t = linspace(0,1-1/Kc,Kc)[k] + U*(1/Kc)
-__device__ __forceinline__ float z_from_t(float t, float near, float far, int lindisp) {
-    if (!lindisp) return near * (1.0f - t) + far * t;
-    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
-}
-
-__device__ __forceinline__ float linspace_k(int k, int n) {
-    // torch.linspace(0, 1-step, n): start + k*(end-start)/(n-1), mirrored from the end in the upper half
-    float step = 1.0f / (float)n;
-    float end = 1.0f - step;
-    if (n == 1) return 0.0f;
-    float inc = end / (float)(n - 1);
-    return (k < n / 2) ? inc * (float)k : end - inc * (float)(n - 1 - k);
-}
-
+// ------------------------------------------------------------------ sample_coarse  (nerf.py:98-118): z_from_t / linspace_k in pnr_common.h
 __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, int Kc, int lindisp,
                                 const float* __restrict__ noise, uint64_t seed, int64_t ray_base,
                                 float* __restrict__ z_out) {
@@ -34,10 +19,7 @@ __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, 
     z_out[idx] = z_from_t(t, near, far, lindisp);
 }
 
-// ------------------------------------------------------------------ composite  (nerf.py:178-182,223-249)
-// One wave per ray.  alpha = 1-exp(-delta*relu(sigma)); T = exclusive cumprod(1-alpha+1e-10);
-// w = alpha*T; rgb = sum w c (+ 1 - sum w if white background); depth = sum w z.
-// The transmittance product is a wave-wide multiplicative scan per 64-sample segment with a carry.
+// ------------------------------------------------------------------ composite  (nerf.py:178-182,223-249): composite_ray in pnr_common.h
 __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ rays, const float* __restrict__ z,
                                                    const float4* __restrict__ rgbs, int64_t n_rays, int K,
                                                    int white_bkgd, float* __restrict__ w_out,
@@ -45,42 +27,16 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ ray
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= n_rays) return;                      // whole wave exits together
-    const float far = rays[ray * 8 + 7];
-    const float* zr = z + ray * K;
-    const float4* cr = rgbs + ray * K;
-    float carry = 1.0f;
-    float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, aw = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        int k = k0 + lane;
-        bool act = k < K;
-        float zk = act ? zr[k] : 0.f;
-        float zn = (k + 1 < K) ? zr[k + 1] : far;   // delta_K = far - z_K
-        float4 c = act ? cr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float delta = zn - zk;
-        float alpha = act ? 1.0f - expf(-delta * fmaxf(c.w, 0.0f)) : 0.0f;
-        float tr = act ? (1.0f - alpha) + 1e-10f : 1.0f;
-        float incl = wave_scan_mul(tr, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        float w = alpha * (carry * excl);
-        carry *= __shfl(incl, 63, 64);
-        if (act && w_out) w_out[ray * K + k] = w;
-        ar += w * c.x; ag += w * c.y; ab += w * c.z; ad += w * zk; aw += w;
-    }
-    ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ad = wave_sum(ad); aw = wave_sum(aw);
+    const float4 r = composite_ray<false>(z + ray * K, rgbs + ray * K, K, rays[ray * 8 + 7], white_bkgd,
+                                          w_out ? w_out + ray * K : nullptr, lane);
     if (lane == 0) {
-        if (white_bkgd) { float bg = 1.0f - aw; ar = ar + bg; ag = ag + bg; ab = ab + bg; }
-        rgb_out[ray * 3 + 0] = ar; rgb_out[ray * 3 + 1] = ag; rgb_out[ray * 3 + 2] = ab;
-        depth_out[ray] = ad;
+        rgb_out[ray * 3 + 0] = r.x; rgb_out[ray * 3 + 1] = r.y; rgb_out[ray * 3 + 2] = r.z;
+        depth_out[ray] = r.w;
     }
 }
 
 // ------------------------------------------------------------------ sample_fine + sample_fine_depth + cat + sort
-// (nerf.py:120-161,285-295).  One wave per ray, wave-private LDS:
-//   cdf[0..Kc]  = [0, cumsum((w+1e-5)/sum(w+1e-5))]
-//   importance: i = #(cdf <= u) - 1 clamped at 0 (NO upper clamp), t = (i + r)/Kc -> z
-//   depth:      z = clamp(depth + g*depth_std, near, far)
-//   merged with z_coarse and sorted ascending (bitonic network over the next power of two, +inf padding).
+// (nerf.py:120-161,285-295): sample_fine_ray in pnr_common.h, one wave per ray, wave-private LDS.
 __global__ void __launch_bounds__(256) k_sample_fine(
     const float* __restrict__ rays, const float* __restrict__ zc, const float* __restrict__ weights,
     const float* __restrict__ depth, int64_t n_rays, int Kc, int n_imp, int n_dep, float depth_std, int lindisp,
@@ -90,81 +46,21 @@ __global__ void __launch_bounds__(256) k_sample_fine(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     const bool live = ray < n_rays;                  // wave-uniform; no early return (barriers below)
-    const int Kt = Kc + n_imp + n_dep;
     float* cdf = smem + (size_t)wv * (P2 + Kc + 2);  // Kc+1 entries
     float* buf = cdf + Kc + 2;                       // P2 entries
-    float near = 0.f, far = 0.f;
-    if (live) { near = rays[ray * 8 + 6]; far = rays[ray * 8 + 7]; }
-
-    // --- cdf
-    float carry = 0.f;
-    if (live && n_imp > 0) {
-        float s = 0.f;
-        for (int k = lane; k < Kc; k += 64) s += weights[ray * Kc + k] + 1e-5f;
-        s = wave_sum(s);
-        if (lane == 0) cdf[0] = 0.f;
-        for (int k0 = 0; k0 < Kc; k0 += 64) {
-            int k = k0 + lane;
-            float p = (k < Kc) ? (weights[ray * Kc + k] + 1e-5f) / s : 0.f;
-            float inc = wave_scan_add(p, lane) + carry;
-            if (k < Kc) cdf[k + 1] = inc;
-            carry = __shfl(inc, 63, 64);
-        }
-    }
-    // --- coarse samples + padding
-    for (int k = lane; k < P2; k += 64) buf[k] = (live && k < Kc) ? zc[ray * Kc + k] : __builtin_inff();
-    __syncthreads();
-    if (live) {
-        // --- importance samples
-        for (int j = lane; j < n_imp; j += 64) {
-            float u = un ? un[ray * n_imp + j] : rng_uniform(seed, ray_base + ray, DRAW_U, j);
-            float r = rn ? rn[ray * n_imp + j] : rng_uniform(seed, ray_base + ray, DRAW_R, j);
-            int cnt = 0;
-            for (int k = 0; k <= Kc; ++k) cnt += (cdf[k] <= u) ? 1 : 0;     // searchsorted(right=True)
-            float ind = fmaxf((float)cnt - 1.0f, 0.0f);
-            float t = (ind + r) / (float)Kc;
-            buf[Kc + j] = z_from_t(t, near, far, lindisp);
-        }
-        // --- depth samples
-        float dpt = n_dep > 0 ? depth[ray] : 0.f;
-        for (int j = lane; j < n_dep; j += 64) {
-            float g = gn ? gn[ray * n_dep + j] : rng_normal(seed, ray_base + ray, DRAW_G, j);
-            float zz = dpt + g * depth_std;
-            buf[Kc + n_imp + j] = fmaxf(fminf(zz, far), near);
-        }
-    }
-    __syncthreads();
-    // --- bitonic sort of buf[0..P2) (ascending); one wave per array, barriers keep LDS ordered
-    for (int sz = 2; sz <= P2; sz <<= 1) {
-        for (int st = sz >> 1; st > 0; st >>= 1) {
-            for (int i = lane; i < (P2 >> 1); i += 64) {
-                int lo = ((i / st) * (st << 1)) + (i % st);
-                int hi = lo + st;
-                bool asc = ((lo & sz) == 0);
-                float a = buf[lo], b = buf[hi];
-                bool sw = asc ? (a > b) : (a < b);
-                if (sw) { buf[lo] = b; buf[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    if (live)
-        for (int k = lane; k < Kt; k += 64) z_out[ray * Kt + k] = buf[k];
+    const int64_t rr = live ? ray : 0;
+    const FineArgs f{Kc, n_imp, n_dep, P2, lindisp, depth_std, un, rn, gn, seed};
+    sample_fine_ray<false>(f, zc + rr * Kc, weights ? weights + rr * Kc : nullptr, (live && n_dep > 0) ? depth[rr] : 0.f,
+                           live ? rays[rr * 8 + 6] : 0.f, live ? rays[rr * 8 + 7] : 0.f, rr, ray_base + rr, live, cdf, buf,
+                           z_out + rr * (Kc + n_imp + n_dep), lane, [] { __syncthreads(); });
 }
 
 // ------------------------------------------------------------------ gen_rays  (util.py:118-148,243-281)
-struct RayCam { float R[9]; float o[3]; float fx, fy, cx, cy, zn, zf; int W, H; };
 __global__ void k_gen_rays(RayCam c, int64_t pix0, int64_t n, float* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int64_t pix = pix0 + i;
-    float y = (float)(pix / c.W), x = (float)(pix % c.W);
-    float X = (x - c.cx) / c.fx, Y = (y - c.cy) / c.fy;
-    float v[3] = {X, -Y, -1.0f};
-    float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    v[0] /= nrm; v[1] /= nrm; v[2] /= nrm;
     float d[3];
-    rot3(c.R, v, d);
+    pinhole_ray(c, (int)(pix0 + i), d);
     float* o = out + i * 8;
     o[0] = c.o[0]; o[1] = c.o[1]; o[2] = c.o[2];
     o[3] = d[0]; o[4] = d[1]; o[5] = d[2];

@@ -600,3 +600,60 @@ def test_sharded_renderer_world1_equals_forward_on_the_hip_renderer():
     rgb2, depth2 = wrapped(rays)
     rend.forced_seed = None
     assert torch.equal(rgb2, ref.fine.rgb)
+
+
+def _staged_render(net, rend, rays):
+    """The passes of NeRFRenderer.forward as SEPARATE launches through the stage entry points (pnr_sample_coarse,
+    pnr_point_mlp on (rays, z), pnr_composite, pnr_sample_fine): what pnr_render did before its launches were fused."""
+    import ctypes as C
+    from pixel_nerf_multiscale_amd import _native as N
+    SB, B, _ = rays.shape
+    dev = rays.device
+    r = N.f32c(rays).reshape(-1, 8)
+    n = SB * B
+    fine = rend.using_fine
+    prec = net.resolved_precision(net.mlp_coarse, net.mlp_fine if fine else None)
+    prm = net.params_struct(rend, prec)
+    v, keep_v = net.views_struct(prec)
+
+    def one_pass(mlp_mod, z):
+        K = z.shape[1]
+        m, keep_m = net.mlp_struct(mlp_mod, prec, v)
+        out = torch.empty(n * K, 4, device=dev)
+        ws = torch.empty(N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(m), C.byref(v), n), dtype=torch.uint8, device=dev)
+        N.check(N.lib.pnr_point_mlp(C.byref(prm), C.byref(m), C.byref(v), N.ptr(r), N.ptr(z), K, None, None, n * K, B * K,
+                                    N.ptr(out), ws.data_ptr(), ws.numel(), N.current_stream(dev)), "pnr_point_mlp")
+        return rend._composite_native(r, z, out)
+
+    zc = rend.sample_coarse(r)
+    res = {"coarse": one_pass(net.mlp_coarse, zc) + (zc,)}
+    if fine:
+        zf = rend.sample_fine_sorted(r, zc, res["coarse"][0], res["coarse"][2])
+        res["fine"] = one_pass(net.mlp_fine if net.mlp_fine is not None else net.mlp_coarse, zf) + (zf,)
+    return res
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", FULL)
+def test_fused_render_launch_is_bit_identical_to_the_staged_launches(name, prec):
+    """pnr_render runs a pass as ONE launch of the MFMA kernel (coarse positions generated in the tile
+    prologue, the network, compositing of every finished ray by the workgroup that evaluated it).  Same arithmetic in the
+    same order as the stage kernels, so pixels, depths, weights and sample positions are BIT-identical to the staged
+    launches — on the reference fixtures (explicit noise tensors) and with in-kernel Philox noise on a ragged ray count."""
+    from hip_util import setup
+    fx, spec, net, rend = setup(name, precision=prec)
+    rend.keep_samples = True
+    rays = _dev(fx["rays"])
+    for mode in ("fixture noise", "kernel rng"):
+        if mode == "kernel rng":
+            rend.fixed_noise = None
+            rend.forced_seed = 4242
+            rays = rays[:, : rays.shape[1] - 3]          # ragged: the last workgroup's range ends inside a tile
+        fused = rend(net, rays, want_weights=True)
+        staged = _staged_render(net, rend, rays)
+        for lvl, (w, rgb, depth, z) in staged.items():
+            SB, B = rays.shape[:2]
+            assert torch.equal(fused[lvl].z.reshape(SB * B, -1), z), (mode, lvl, "z")
+            assert torch.equal(fused[lvl].weights.reshape(SB * B, -1), w), (mode, lvl, "weights")
+            assert torch.equal(fused[lvl].rgb.reshape(SB * B, 3), rgb), (mode, lvl, "rgb")
+            assert torch.equal(fused[lvl].depth.reshape(SB * B), depth), (mode, lvl, "depth")
