@@ -246,6 +246,17 @@ int32_t pnr_sample_fine_bwd(const float* rays, const float* depth, int64_t n_ray
                             uint64_t seed, int64_t ray_index_base, const float* z_sorted,
                             const float* d_z_sorted, float* d_depth, void* stream);
 
+/* pnr_render for the rays of ONE camera, generated inside the render launch (util.gen_rays, util/util.py:118-148,243-281, then
+ * NeRFRenderer.forward): ray i is pixel pix0 + i (row-major) of the W x H pinhole image of camera-to-world matrix c2w.
+ * What the reference's eval drivers do per frame (eval/eval.py:250-293: gen_rays on the host, H2D, split, render_par per
+ * chunk) as one call with no ray tensor.  views->n_objs must be 1.  Results are bit-identical to pnr_gen_rays + pnr_render.
+ * ray_index_base counts rays for the in-kernel noise exactly as in pnr_render (pass pix0 when sharding one frame). */
+int32_t pnr_render_camera(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
+                          const pnr_views* views, const float* c2w /* host, 16 floats */, int32_t W, int32_t H,
+                          float fx, float fy, float cx, float cy, float z_near, float z_far, int64_t pix0,
+                          int64_t n_rays, const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
+                          const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream);
+
 /* util.gen_rays for one camera (util/util.py:118-148,243-281): pixels [pix0, pix0+n) of a W x H pinhole image. */
 int32_t pnr_gen_rays(const float* c2w /* host, 16 floats */, int32_t W, int32_t H, float fx, float fy,
                      float cx, float cy, float z_near, float z_far, int64_t pix0, int64_t n,

@@ -92,6 +92,9 @@ PROTOTYPES = {
     "pnr_workspace_bytes": (_u64, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_render": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _i64,
                           _i64, C.POINTER(pnr_noise), _u64, _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),
+    "pnr_render_camera": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_mlp), C.POINTER(pnr_views),
+                                 C.POINTER(C.c_float), _i32, _i32, _f, _f, _f, _f, _f, _f, _i64, _i64, C.POINTER(pnr_noise), _u64,
+                                 _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),
     "pnr_train_tape_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_train_bwd_workspace_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_point_mlp_train_fwd": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _fp, _i32,

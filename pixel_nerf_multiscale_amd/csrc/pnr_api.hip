@@ -6,6 +6,11 @@ namespace pnr {
 uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+// stage_kernels.hip
+int32_t sample_fine_launch(const float* rays, float near_all, float far_all, const float* z_coarse, const float* weights,
+                           const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
+                           float depth_std, int32_t lindisp, const float* u, const float* r, const float* g, uint64_t seed,
+                           int64_t ray_index_base, float* z_out, void* stream);
 // point_mfma.hip
 uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
@@ -168,7 +173,7 @@ extern "C" int32_t pnr_point_mlp_bwd(const pnr_params* params, const pnr_mlp* ml
                      d_xyz, d_z, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-struct RenderWs { uint64_t zc, zf, rgbs, w, rgb, depth, point, total; };
+struct RenderWs { uint64_t zc, zf, rgbs, w, rgb, depth, rays, point, total; };
 
 // `fine` (may be NULL): the point workspace is shared by both passes, so it is sized for the larger of the two MLPs
 static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t n, const pnr_mlp* fine = nullptr) {
@@ -180,6 +185,7 @@ static RenderWs carve(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views
     r.w = off; off += align256(n * Kt * 4);
     r.rgb = off; off += align256(n * 12);
     r.depth = off; off += align256(n * 4);
+    r.rays = off; off += align256(n * 32);          // pnr_render_camera on the fp32 path materialises its rays here
     uint64_t pw = point_workspace_bytes(prm, mlp, vw);
     if (fine) { uint64_t pf = point_workspace_bytes(prm, fine, vw); if (pf > pw) pw = pf; }
     r.point = off; off += align256(pw);
@@ -193,14 +199,15 @@ extern "C" uint64_t pnr_workspace_bytes(const pnr_params* params, const pnr_mlp*
     return carve(params, mlp, views, n_rays).total;
 }
 
-extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
-                              const pnr_views* views, const float* rays, int64_t n_rays, int64_t rays_per_obj,
-                              const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
-                              const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream) {
+// pnr_render / pnr_render_camera: `rays` or `cam` (+ first pixel)
+static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine, const pnr_views* views,
+                           const float* rays, const RayCam* cam, int64_t pix0, int64_t n_rays, int64_t rays_per_obj,
+                           const pnr_noise* noise, uint64_t seed, int64_t ray_index_base, const pnr_outputs* outputs,
+                           void* workspace, uint64_t workspace_bytes, void* stream) {
     int32_t rc = check_model(params, coarse, views);
     if (rc) return rc;
     if (fine && (rc = check_model(params, fine, views))) return rc;
-    if (!rays || !outputs) return PNR_E_NULL;
+    if ((!rays && !cam) || !outputs) return PNR_E_NULL;
     if (params->n_coarse < 1 || params->n_fine < 0 || params->n_fine_depth < 0 ||
         params->n_fine_depth > params->n_fine) return PNR_E_SHAPE;
     if (n_rays < 0 || rays_per_obj <= 0 || n_rays != rays_per_obj * views->n_objs) return PNR_E_SHAPE;
@@ -220,24 +227,26 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     void* pws = base + cw.point;
     uint64_t pws_bytes = workspace_bytes - (uint64_t)((char*)pws - (char*)workspace);
     const pnr_noise nz = noise ? *noise : pnr_noise{nullptr, nullptr, nullptr, nullptr};
-
     if (Kf > 0 && (!outputs->fine_rgb || !outputs->fine_depth)) return PNR_E_NULL;
 
     if (params->precision != PNR_F32) {
-        // The MFMA kernel renders a pass in ONE launch: coarse positions generated in the tile prologue, the network, and the
-        // compositing of every finished ray by the workgroup that evaluated it (point_mfma.hip).  Between the passes one small
-        // launch resamples (a 256-element sort per ray has no place between two MFMA tiles).
+        // The MFMA kernel renders a pass in ONE launch: rays from the camera (if any) and coarse positions generated in the tile
+        // prologue, the network, and the compositing of every finished ray by the workgroup that evaluated it
+        // (point_mfma.hip).  Between the passes one small launch resamples (a 256-element sort per ray has no place
+        // between two MFMA tiles).
         RayJob job{};
         job.on = 1; job.K = Kc; job.gen_z = 1; job.lindisp = params->lindisp; job.white_bkgd = params->white_bkgd;
         job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.ray_base = ray_index_base;
         job.z_out = zc; job.w_out = w_c; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        if (cam) { job.from_cam = 1; job.cam = *cam; job.pix0 = (int)pix0; }
         PointSrc src{rays, nullptr, Kc, nullptr, nullptr};
         if (outputs->ev_point_begin) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_begin, s));
         if ((rc = point_mfma(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s, &job))) return rc;
         if (outputs->ev_point_end) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_end, s));
         if (Kf == 0) return PNR_OK;
-        if ((rc = pnr_sample_fine(rays, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
-                                  nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream))) return rc;
+        if ((rc = sample_fine_launch(rays, cam ? cam->zn : 0.f, cam ? cam->zf : 0.f, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd,
+                                     params->depth_std, params->lindisp, nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream)))
+            return rc;
         job.K = Kt; job.gen_z = 0; job.noise_c = nullptr; job.z_out = nullptr;
         job.w_out = outputs->fine_weights; job.rgb_out = outputs->fine_rgb; job.depth_out = outputs->fine_depth;
         PointSrc srcf{rays, zf, Kt, nullptr, nullptr};
@@ -245,6 +254,15 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
     }
 
     // fp32 path: the stages as separate launches
+    if (!rays) {
+        float* rbuf = (float*)(base + cw.rays);
+        // c2w back from the RayCam for the stage entry point
+        const float m[16] = {cam->R[0], cam->R[1], cam->R[2], cam->o[0], cam->R[3], cam->R[4], cam->R[5], cam->o[1],
+                             cam->R[6], cam->R[7], cam->R[8], cam->o[2], 0.f, 0.f, 0.f, 1.f};
+        if ((rc = pnr_gen_rays(m, cam->W, cam->H, cam->fx, cam->fy, cam->cx, cam->cy, cam->zn, cam->zf, pix0, n_rays, rbuf, stream)))
+            return rc;
+        rays = rbuf;
+    }
     // coarse pass (nerf.py:273-282)
     if ((rc = pnr_sample_coarse(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, ray_index_base, zc, stream))) return rc;
     PointSrc src{rays, zc, Kc, nullptr, nullptr};
@@ -262,6 +280,29 @@ extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, c
                              pws_bytes, s))) return rc;
     return pnr_composite(rays, zf, rgbs, n_rays, Kt, params->white_bkgd, outputs->fine_weights, outputs->fine_rgb,
                          outputs->fine_depth, stream);
+}
+
+extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
+                              const pnr_views* views, const float* rays, int64_t n_rays, int64_t rays_per_obj,
+                              const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
+                              const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream) {
+    if (!rays) return PNR_E_NULL;
+    return render_impl(params, coarse, fine, views, rays, nullptr, 0, n_rays, rays_per_obj, noise, seed, ray_index_base,
+                       outputs, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t pnr_render_camera(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,
+                                     const pnr_views* views, const float* c2w, int32_t W, int32_t H, float fx, float fy,
+                                     float cx, float cy, float z_near, float z_far, int64_t pix0, int64_t n_rays,
+                                     const pnr_noise* noise, uint64_t seed, int64_t ray_index_base,
+                                     const pnr_outputs* outputs, void* workspace, uint64_t workspace_bytes, void* stream) {
+    if (!c2w || !views) return PNR_E_NULL;
+    if (W <= 0 || H <= 0 || n_rays < 0 || pix0 < 0 || pix0 + n_rays > (int64_t)W * H || (int64_t)W * H > 0x7fffffffLL)
+        return PNR_E_SHAPE;
+    if (views->n_objs != 1) return PNR_E_SHAPE;          // one camera looks at one object
+    const RayCam cam = make_ray_cam(c2w, W, H, fx, fy, cx, cy, z_near, z_far);
+    return render_impl(params, coarse, fine, views, nullptr, &cam, pix0, n_rays, n_rays, noise, seed, ray_index_base,
+                       outputs, workspace, workspace_bytes, stream);
 }
 
 // ---- hipEvent helpers for ctypes callers (bench.py times kernels on the stream they run on)

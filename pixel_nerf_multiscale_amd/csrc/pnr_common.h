@@ -122,10 +122,13 @@ __device__ __forceinline__ Cam load_cam(const pnr_views& vw, int view) {
     return c;
 }
 
+// Explicit fma chains here and in the per-ray stages below: under hipcc's default -ffp-contract=fast a sum of products may be
+// fused either way round, and which way depends on the surrounding code — the same source line inlined into two kernels
+// then differs in the last bit.  The fused render launch is bit-identical to the stage kernels only with the order spelled out.
 __device__ __forceinline__ void rot3(const float* R, const float* v, float* o) {
-    o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
-    o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
-    o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = fmaf(R[2], v[2], fmaf(R[1], v[1], R[0] * v[0]));
+    o[1] = fmaf(R[5], v[2], fmaf(R[4], v[1], R[3] * v[0]));
+    o[2] = fmaf(R[8], v[2], fmaf(R[7], v[1], R[6] * v[0]));
 }
 
 // uv in image pixels: -x_cam.xy / x_cam.z * (fx, fy) + c   (models.py.backup2:215-221)
@@ -203,8 +206,8 @@ __device__ __forceinline__ float posenc_elem(const float* x, int d, int j, float
 // (shared by the stage kernels of stage_kernels.hip and by the fused render launch of point_mfma.hip)
 // sample_coarse (nerf.py:98-118): z = near(1-t)+far*t  (or 1/((1-t)/near + t/far)),  t = linspace(0,1-1/Kc,Kc)[k] + U*(1/Kc)
 __device__ __forceinline__ float z_from_t(float t, float near, float far, int lindisp) {
-    if (!lindisp) return near * (1.0f - t) + far * t;
-    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+    if (!lindisp) return fmaf(far, t, near * (1.0f - t));
+    return 1.0f / fmaf(1.0f / far, t, (1.0f / near) * (1.0f - t));
 }
 __device__ __forceinline__ float linspace_k(int k, int n) {
     // torch.linspace(0, 1-step, n): start + k*(end-start)/(n-1), mirrored from the end in the upper half
@@ -212,17 +215,26 @@ __device__ __forceinline__ float linspace_k(int k, int n) {
     float end = 1.0f - step;
     if (n == 1) return 0.0f;
     float inc = end / (float)(n - 1);
-    return (k < n / 2) ? inc * (float)k : end - inc * (float)(n - 1 - k);
+    return (k < n / 2) ? inc * (float)k : fmaf(-inc, (float)(n - 1 - k), end);
 }
 
 // gen_rays (util.py:118-148,243-281): pinhole camera looking down -z, pixel -> world ray
 struct RayCam { float R[9]; float o[3]; float fx, fy, cx, cy, zn, zf; int W, H; };
+inline RayCam make_ray_cam(const float* c2w /* host, row-major 4x4 */, int W, int H, float fx, float fy, float cx, float cy,
+                           float z_near, float z_far) {
+    RayCam c;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c.R[i * 3 + j] = c2w[i * 4 + j];
+        c.o[i] = c2w[i * 4 + 3];
+    }
+    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.zn = z_near; c.zf = z_far; c.W = W; c.H = H;
+    return c;
+}
 __device__ __forceinline__ void pinhole_ray(const RayCam& c, int pix, float* d) {
     float y = (float)(pix / c.W), x = (float)(pix % c.W);
     float X = (x - c.cx) / c.fx, Y = (y - c.cy) / c.fy;
-    float v[3] = {X, -Y, -1.0f};
-    float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    v[0] /= nrm; v[1] /= nrm; v[2] /= nrm;
+    float nrm = sqrtf(fmaf(X, X, fmaf(Y, Y, 1.0f)));
+    float v[3] = {X / nrm, -Y / nrm, -1.0f / nrm};
     rot3(c.R, v, d);
 }
 
@@ -260,7 +272,7 @@ __device__ __forceinline__ float4 composite_ray(const float* zr, const float4* c
         float w = alpha * (carry * excl);
         carry *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
         if (act && wr) wr[k] = w;
-        ar += w * c.x; ag += w * c.y; ab += w * c.z; ad += w * zk; aw += w;
+        ar = fmaf(w, c.x, ar); ag = fmaf(w, c.y, ag); ab = fmaf(w, c.z, ab); ad = fmaf(w, zk, ad); aw += w;
     }
     ar = wave_sum_l(ar, lane); ag = wave_sum_l(ag, lane); ab = wave_sum_l(ab, lane); ad = wave_sum_l(ad, lane);
     aw = wave_sum_l(aw, lane);
@@ -310,7 +322,7 @@ __device__ __forceinline__ void sample_fine_ray(const FineArgs& f, const float* 
         }
         for (int j = lane; j < n_dep; j += 64) {
             float g = f.gn ? f.gn[ray_local * n_dep + j] : rng_normal(f.seed, ray_global, DRAW_G, j);
-            float zz = depth + g * f.depth_std;
+            float zz = fmaf(g, f.depth_std, depth);
             buf[Kc + n_imp + j] = fmaxf(fminf(zz, far), near);
         }
     }
@@ -358,7 +370,7 @@ __device__ __forceinline__ void fetch_point(const PointSrc& s, int64_t g, float*
         const float* r = s.rays + ray * 8;
         float z = s.z[g];
         d[0] = r[3]; d[1] = r[4]; d[2] = r[5];
-        p[0] = r[0] + z * d[0]; p[1] = r[1] + z * d[1]; p[2] = r[2] + z * d[2];
+        p[0] = fmaf(z, d[0], r[0]); p[1] = fmaf(z, d[1], r[1]); p[2] = fmaf(z, d[2], r[2]);
     } else {
         p[0] = s.xyz[g * 3 + 0]; p[1] = s.xyz[g * 3 + 1]; p[2] = s.xyz[g * 3 + 2];
         d[0] = s.dirs[g * 3 + 0]; d[1] = s.dirs[g * 3 + 1]; d[2] = s.dirs[g * 3 + 2];

@@ -687,13 +687,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                             const int64_t gp = p_begin + li;
                             const float u = a.job.noise_c ? a.job.noise_c[gp]
                                                           : rng_uniform(a.job.seed, a.job.ray_base + ray_begin + lr, DRAW_COARSE, k);
-                            const float t = linspace_k(k, Kq) + u * (1.0f / (float)Kq);
+                            const float t = fmaf(u, 1.0f / (float)Kq, linspace_k(k, Kq));
                             zz = z_from_t(t, near, far, a.job.lindisp);
                             if (v == 0 && g == 0 && in_range) a.job.z_out[gp] = zz;
                         } else {
                             zz = *(const float*)(pts + 1024 + pl * 4);
                         }
-                        p[0] = o3[0] + zz * d[0]; p[1] = o3[1] + zz * d[1]; p[2] = o3[2] + zz * d[2];
+                        p[0] = fmaf(zz, d[0], o3[0]); p[1] = fmaf(zz, d[1], o3[1]); p[2] = fmaf(zz, d[2], o3[2]);
                     } else {
                         const float* q3 = (const float*)(pts + pl * 4);
                         p[0] = q3[0]; p[1] = q3[64]; p[2] = q3[128];

@@ -15,7 +15,7 @@ __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, 
     int k = (int)(idx % Kc);
     float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
     float u = noise ? noise[idx] : rng_uniform(seed, ray_base + ray, DRAW_COARSE, k);
-    float t = linspace_k(k, Kc) + u * (1.0f / (float)Kc);
+    float t = fmaf(u, 1.0f / (float)Kc, linspace_k(k, Kc));
     z_out[idx] = z_from_t(t, near, far, lindisp);
 }
 
@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_sample_fine(
     const float* __restrict__ rays, const float* __restrict__ zc, const float* __restrict__ weights,
     const float* __restrict__ depth, int64_t n_rays, int Kc, int n_imp, int n_dep, float depth_std, int lindisp,
     const float* __restrict__ un, const float* __restrict__ rn, const float* __restrict__ gn,
-    uint64_t seed, int64_t ray_base, float* __restrict__ z_out, int P2 /* pow2 >= Kc+n_imp+n_dep */) {
+    uint64_t seed, int64_t ray_base, float* __restrict__ z_out, int P2 /* pow2 >= Kc+n_imp+n_dep */,
+    float near_all, float far_all /* the bounds of every ray when rays == NULL (rays of one camera) */) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
@@ -51,7 +52,8 @@ __global__ void __launch_bounds__(256) k_sample_fine(
     const int64_t rr = live ? ray : 0;
     const FineArgs f{Kc, n_imp, n_dep, P2, lindisp, depth_std, un, rn, gn, seed};
     sample_fine_ray<false>(f, zc + rr * Kc, weights ? weights + rr * Kc : nullptr, (live && n_dep > 0) ? depth[rr] : 0.f,
-                           live ? rays[rr * 8 + 6] : 0.f, live ? rays[rr * 8 + 7] : 0.f, rr, ray_base + rr, live, cdf, buf,
+                           !rays ? near_all : live ? rays[rr * 8 + 6] : 0.f, !rays ? far_all : live ? rays[rr * 8 + 7] : 0.f,
+                           rr, ray_base + rr, live, cdf, buf,
                            z_out + rr * (Kc + n_imp + n_dep), lane, [] { __syncthreads(); });
 }
 
@@ -71,7 +73,6 @@ __global__ void k_gen_rays(RayCam c, int64_t pix0, int64_t n, float* __restrict_
 
 using namespace pnr;
 
-static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 extern "C" int32_t pnr_sample_coarse(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp,
                                      const float* noise_c, uint64_t seed, int64_t ray_index_base,
@@ -99,12 +100,15 @@ extern "C" int32_t pnr_composite(const float* rays, const float* z, const float*
     return PNR_OK;
 }
 
-extern "C" int32_t pnr_sample_fine(const float* rays, const float* z_coarse, const float* weights,
-                                   const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine,
-                                   int32_t n_fine_depth, float depth_std, int32_t lindisp, const float* u,
-                                   const float* r, const float* g, uint64_t seed, int64_t ray_index_base,
-                                   float* z_out, void* stream) {
-    if (!rays || !z_coarse || !z_out) return PNR_E_NULL;
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+namespace pnr {
+// rays == NULL: every ray has the bounds (near_all, far_all) — the rays of one camera (pnr_render_camera)
+int32_t sample_fine_launch(const float* rays, float near_all, float far_all, const float* z_coarse, const float* weights,
+                           const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
+                           float depth_std, int32_t lindisp, const float* u, const float* r, const float* g, uint64_t seed,
+                           int64_t ray_index_base, float* z_out, void* stream) {
+    if (!z_coarse || !z_out) return PNR_E_NULL;
     if (n_rays < 0 || n_coarse <= 0 || n_fine < 0 || n_fine_depth < 0 || n_fine_depth > n_fine) return PNR_E_SHAPE;
     int n_imp = n_fine - n_fine_depth;
     if (n_imp > 0 && !weights) return PNR_E_NULL;
@@ -119,22 +123,28 @@ extern "C" int32_t pnr_sample_fine(const float* rays, const float* z_coarse, con
         PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_sample_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_sample_fine, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, (hipStream_t)stream,
                        rays, z_coarse, weights, depth, n_rays, n_coarse, n_imp, n_fine_depth, depth_std, lindisp,
-                       u, r, g, seed, ray_index_base, z_out, P2);
+                       u, r, g, seed, ray_index_base, z_out, P2, near_all, far_all);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
+}
+}  // namespace pnr
+
+extern "C" int32_t pnr_sample_fine(const float* rays, const float* z_coarse, const float* weights,
+                                   const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine,
+                                   int32_t n_fine_depth, float depth_std, int32_t lindisp, const float* u,
+                                   const float* r, const float* g, uint64_t seed, int64_t ray_index_base,
+                                   float* z_out, void* stream) {
+    if (!rays) return PNR_E_NULL;
+    return sample_fine_launch(rays, 0.f, 0.f, z_coarse, weights, depth, n_rays, n_coarse, n_fine, n_fine_depth, depth_std,
+                              lindisp, u, r, g, seed, ray_index_base, z_out, stream);
 }
 
 extern "C" int32_t pnr_gen_rays(const float* c2w, int32_t W, int32_t H, float fx, float fy, float cx, float cy,
                                 float z_near, float z_far, int64_t pix0, int64_t n, float* rays_out, void* stream) {
     if (!c2w || !rays_out) return PNR_E_NULL;
-    if (W <= 0 || H <= 0 || n < 0 || pix0 < 0 || pix0 + n > (int64_t)W * H) return PNR_E_SHAPE;
+    if (W <= 0 || H <= 0 || n < 0 || pix0 < 0 || pix0 + n > (int64_t)W * H || (int64_t)W * H > 0x7fffffffLL) return PNR_E_SHAPE;
     if (n == 0) return PNR_OK;
-    RayCam c;
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) c.R[i * 3 + j] = c2w[i * 4 + j];
-        c.o[i] = c2w[i * 4 + 3];
-    }
-    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.zn = z_near; c.zf = z_far; c.W = W; c.H = H;
+    const RayCam c = make_ray_cam(c2w, W, H, fx, fy, cx, cy, z_near, z_far);
     hipLaunchKernelGGL(k_gen_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c, pix0, n, rays_out);
     PNR_LAUNCH_CHECK();
     return PNR_OK;

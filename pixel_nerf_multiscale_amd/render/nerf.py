@@ -180,10 +180,16 @@ class NeRFRenderer(torch.nn.Module):
             raise NotImplementedError("sigma noise (nerf.py:225-226) exists on the differentiable path only")
         return self._forward_generic(model, rays, want_weights)
 
-    def _forward_fused(self, net, rays, want_weights):
-        SB, B, _ = rays.shape
-        dev = N.same_device(rays, net.poses)
-        rays_f = N.f32c(rays).reshape(-1, 8)
+    def _forward_fused(self, net, rays, want_weights, camera=None):
+        """rays (SB, B, 8) through pnr_render; or, with rays=None, the pixels of `camera` = (c2w 16 floats, W, H, fx, fy,
+        cx, cy, z_near, z_far, pix0, n) through pnr_render_camera (rays generated inside the render launch)."""
+        if camera is None:
+            SB, B, _ = rays.shape
+            dev = N.same_device(rays, net.poses)
+            rays_f = N.f32c(rays).reshape(-1, 8)
+        else:
+            SB, B = 1, int(camera[10])
+            dev = net.poses.device
         n = SB * B
         Kc, Kf = int(self.n_coarse), int(self.n_fine) if self.using_fine else 0
         # one precision per call: the fused kernel only when BOTH MLPs of this call have a shape it is built for
@@ -222,9 +228,16 @@ class NeRFRenderer(torch.nn.Module):
         if mf is not None:      # the point workspace serves both passes: size it for the larger MLP
             nbytes = max(nbytes, N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mf), C.byref(v), n))
         ws = net.workspace(nbytes, dev)
-        N.check(N.lib.pnr_render(C.byref(prm), C.byref(mc), C.byref(mf) if mf is not None else None, C.byref(v),
-                                 N.ptr(rays_f), n, B, C.byref(nz), self._seed(), int(self.ray_index_base), C.byref(o),
-                                 ws.data_ptr(), ws.numel(), N.current_stream(dev)), "pnr_render")
+        if camera is None:
+            N.check(N.lib.pnr_render(C.byref(prm), C.byref(mc), C.byref(mf) if mf is not None else None, C.byref(v),
+                                     N.ptr(rays_f), n, B, C.byref(nz), self._seed(), int(self.ray_index_base), C.byref(o),
+                                     ws.data_ptr(), ws.numel(), N.current_stream(dev)), "pnr_render")
+        else:
+            m, W, H, fx, fy, cx, cy, zn, zf, pix0, _ = camera
+            N.check(N.lib.pnr_render_camera(C.byref(prm), C.byref(mc), C.byref(mf) if mf is not None else None, C.byref(v),
+                                            (C.c_float * 16)(*m), W, H, fx, fy, cx, cy, zn, zf, pix0, n, C.byref(nz),
+                                            self._seed(), int(self.ray_index_base), C.byref(o), ws.data_ptr(), ws.numel(),
+                                            N.current_stream(dev)), "pnr_render_camera")
         return res
 
     def _forward_generic(self, model, rays, want_weights):
@@ -242,12 +255,27 @@ class NeRFRenderer(torch.nn.Module):
     def render_image(self, net, pose, width, height, focal, z_near, z_far, c=None):
         """One target view in one call — what the eval drivers do per frame (reference eval/eval.py:250-293:
         gen_rays on the host, H2D, split into ray batches, render_par per chunk with a .cpu() sync each):
-        rays are generated on the GPU (pnr_gen_rays), the whole frame is one pnr_render, nothing touches the host.
+        the whole frame is one pnr_render_camera: the rays are generated inside the render launch from the camera
+        (no ray tensor, nothing touches the host); bit-identical to util.gen_rays_device + forward.  A model that needs
+        the differentiable path gets its rays from pnr_gen_rays and goes through forward.
         pose: (4,4) camera-to-world.  Returns rgb (H, W, 3), depth (H, W) on the device."""
         from .. import util
+        from ..model.models import PixelNeRFNet
         dev = net.poses.device
-        rays = util.gen_rays_device(pose, width, height, focal, z_near, z_far, c=c, device=dev)
-        out = self(net, rays[None])
+        if not isinstance(net, PixelNeRFNet) or net.num_objs != 1 or net.wants_grad(net.poses):
+            rays = util.gen_rays_device(pose, width, height, focal, z_near, z_far, c=c, device=dev)
+            out = self(net, rays[None])
+        else:
+            if self.sched is not None and self.last_sched.item() > 0:
+                self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+                self.n_fine = self.sched[2][self.last_sched.item() - 1]
+            f = torch.as_tensor(focal, dtype=torch.float32).flatten()
+            cc = None if c is None else torch.as_tensor(c, dtype=torch.float32).flatten()
+            cx, cy = (width * 0.5, height * 0.5) if cc is None else (float(cc[0]), float(cc[1]))
+            m = [float(x) for x in torch.as_tensor(pose, dtype=torch.float32).cpu().flatten().tolist()]
+            cam = (m, int(width), int(height), float(f[0]), float(f[-1]), cx, cy, float(z_near), float(z_far), 0,
+                   int(width) * int(height))
+            out = self._forward_fused(net, None, False, camera=cam)
         lvl = out.fine if self.using_fine else out.coarse
         return lvl.rgb.reshape(height, width, 3), lvl.depth.reshape(height, width)
 

@@ -657,3 +657,24 @@ def test_fused_render_launch_is_bit_identical_to_the_staged_launches(name, prec)
             assert torch.equal(fused[lvl].weights.reshape(SB * B, -1), w), (mode, lvl, "weights")
             assert torch.equal(fused[lvl].rgb.reshape(SB * B, 3), rgb), (mode, lvl, "rgb")
             assert torch.equal(fused[lvl].depth.reshape(SB * B), depth), (mode, lvl, "depth")
+
+
+@pytest.mark.parametrize("name,prec", [("full_ns1", "bf16"), ("full_ns3", "fp16"), ("full_dtu_ns3", "bf16"), ("tiny_ns2_codeview", "fp32")])
+def test_rays_generated_inside_the_render_launch_are_bit_identical(name, prec):
+    """N1: NeRFRenderer.render_image -> pnr_render_camera: the MFMA kernel forms each point's ray from (c2w, intrinsics, pixel
+    index) in its tile prologue; no ray tensor exists.  Bit-identical to pnr_gen_rays + forward on those rays (same in-kernel
+    noise), for both principal-point conventions and a non-square image; the fp32 path materialises the rays in the workspace."""
+    from hip_util import setup
+    from pixel_nerf_multiscale_amd import util
+    fx, spec, net, rend = setup(name, precision=prec)
+    rend.fixed_noise = None
+    rend.forced_seed = 31
+    pose = util.pose_spherical(40.0, -30.0, spec["radius"])
+    for (W, H, c) in ((24, 17, None), (19, 23, (9.25, 12.5))):
+        f = (spec["focal"], spec["focal"] * 1.1)
+        rgb, depth = rend.render_image(net, pose, W, H, f, spec["z_near"], spec["z_far"], c=c)
+        rays = util.gen_rays_device(pose, W, H, f, spec["z_near"], spec["z_far"], c=c, device="cuda")
+        ref = rend(net, rays[None])
+        lvl = ref.fine if rend.using_fine else ref.coarse
+        assert torch.equal(rgb.reshape(-1, 3), lvl.rgb.reshape(-1, 3)), (W, H)
+        assert torch.equal(depth.reshape(-1), lvl.depth.reshape(-1)), (W, H)
