@@ -276,6 +276,8 @@ struct MfmaArgs {
     const char* lat[PNR_MAX_LEVELS];   // packed latents per level
     float* out;
     float4* spill;                 // (grid, 4 waves, NS-1, 64 x 64) float4
+    char* gcache;                  // (grid, 4 waves, n_cached, 16 KiB): a view's gathered lin_z images, kept for its later blocks
+    int n_cached;
     int n_tiles, NS, combine_max;
     int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj, Gg;
     int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
@@ -303,6 +305,16 @@ __device__ __forceinline__ void glds_stage(const char* g_base /* wave-uniform */
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+}
+
+// 4 KiB of a wave's own workspace data back into LDS (the cached lin_z images): as glds_stage, but through the L2 — the lines
+// were written by this wave a block ago and read a tile ago, so the CU's L1 may hold their previous contents.
+__device__ __forceinline__ void glds_stage_l2(const char* g_base /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 sc1\n\t"
                  "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
@@ -390,7 +402,18 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     };
     // ---------------- this workgroup's points [p_begin, p_end): whole rays in a fused render launch (so that a ray is composited
     // by the workgroup that evaluated it), whole tiles otherwise.  The host keeps p_end - p_begin below 2^31.
-    const bool ray_mode = a.src.rays != nullptr || a.job.from_cam;
+    // Launch-uniform switches are read through an opaque copy where they are tested: hipcc otherwise evaluates them once at the
+    // kernel's entry, keeps the 0/1 results in VECTOR registers (the scalar file is full) and, those being clobbered by the
+    // asm blocks, reloads them from scratch in every tile — with a vmcnt(0) that also drains the run-ahead LDS-DMA.
+    auto flag = [](int v) __attribute__((always_inline)) -> bool {
+        v = __builtin_amdgcn_readfirstlane(v);
+        asm volatile("" : "+s"(v));
+        return v != 0;
+    };
+    auto flagp = [](const void* q) __attribute__((always_inline)) -> bool {
+        asm volatile("" : "+s"(q));
+        return q != nullptr;
+    };
     int64_t p_begin, p_end, ray_begin = 0;
     if (a.job.on) {
         ray_begin = (int64_t)blockIdx.x * a.job.rays_per_wg;
@@ -417,13 +440,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         int lp = tile * TILE_PTS + wv * 32 + (lane & 31);            // index within the workgroup's range
         lp = lp < n_loc ? lp : n_loc - 1;
         const int64_t gp = p_begin + lp;
-        if (a.job.on) {
+        if (flag(a.job.on)) {
             int Kq = a.job.K;
             asm volatile("" : "+s"(Kq));
             const int64_t ray = ray_begin + (uint32_t)lp / (uint32_t)Kq;
-            if (!a.job.from_cam) glds_gather_ray_only(a.src.rays + ray * 8 + (lane >> 5) * 4, dst);
-            if (!a.job.gen_z) glds_gather_z_only((const char*)(a.src.z + gp) - 1024, dst);
-        } else if (a.src.rays) {
+            if (!flag(a.job.from_cam)) glds_gather_ray_only(a.src.rays + ray * 8 + (lane >> 5) * 4, dst);
+            if (!flag(a.job.gen_z)) glds_gather_z_only((const char*)(a.src.z + gp) - 1024, dst);
+        } else if (flagp(a.src.rays)) {
             const int64_t ray = div_pts(gp, a.src.K);
             glds_gather_ray(a.src.rays + ray * 8 + (lane >> 5) * 4, (const char*)(a.src.z + gp) - 1024, dst);
         } else {
@@ -504,8 +527,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         const int K = a.job.K;
         for (int lr = lr0 + ((wv - lr0) & 3); lr < lr1; lr += 4) {
             const int64_t ray = ray_begin + lr;
-            const float far = a.job.from_cam ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
-            const float* zr = (a.job.gen_z ? a.job.z_out : a.src.z) + ray * K;
+            const float far = flag(a.job.from_cam) ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
+            const float* zr = (flag(a.job.gen_z) ? a.job.z_out : a.src.z) + ray * K;
             const float4 r = composite_ray<true>(zr, (const float4*)a.out + ray * K, K, far, a.job.white_bkgd,
                                                  a.job.w_out ? a.job.w_out + ray * K : nullptr, lane);
             if (lane == 0) {
@@ -537,7 +560,18 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         int v = 0;      // current source-view pass
         // ---- latent gather: group grp (256 channels) -> this wave's LDS B image [k-step][column group][lane][8]:
         //      lane (g, c) interpolates channels 32 ks + 8 g .. + 7 of its two points
-        auto gather = [&](int grp) __attribute__((always_inline)) {
+        // With several lin_z parts per block the one LDS image is rebuilt for every part of every block: the gather runs for
+        // the view's first block only and leaves a copy in the workspace (`keep`), which the later blocks fetch back by
+        // LDS-DMA (restore) instead of interpolating again.
+        char* cache_wave = a.gcache + (size_t)(blockIdx.x * 4 + wv) * a.n_cached * ZBUF_BYTES;
+        auto restore = [&](int grp) __attribute__((always_inline)) {
+            const uint32_t lane16 = lane_id() * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(zwave));
+#pragma unroll
+            for (int i = 0; i < ZBUF_BYTES / 4096; ++i)
+                glds_stage_l2(cache_wave + (size_t)grp * ZBUF_BYTES + i * 4096, lane16, dst + i * 4096);
+        };
+        auto gather = [&](int grp, bool keep) __attribute__((always_inline)) {
             const int lane = lane_id(), c = lane & 15, g = lane >> 4;
             const float4 uv4 = uvw[lane];
             const float pu[2] = {uv4.x, uv4.z}, pv[2] = {uv4.y, uv4.w};
@@ -581,6 +615,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                                     o.z = NM::pack(acc8[4], acc8[5]); o.w = NM::pack(acc8[6], acc8[7]);
                                     const int ks = (ch - grp * 256) >> 5;
                                     *(uint4*)(zwave + (ks * 2 + cg) * 1024 + lane * 16) = o;
+                                    if (keep) *(uint4*)(cache_wave + (size_t)grp * ZBUF_BYTES + (ks * 2 + cg) * 1024 + lane * 16) = o;
                                 }
                             }
                         }
@@ -659,7 +694,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     const Cam cam = a.vw.n_objs == 1 ? load_cam(a.vw, __builtin_amdgcn_readfirstlane(v)) : load_cam(a.vw, view_of(c, cg, v));
                     float p[3], d[3], xr[3], dr[3];
                     const int pl = 16 * cg + c;
-                    if (ray_mode) {
+                    if ((flag(a.job.from_cam) || flagp(a.src.rays))) {
                         float o3[3], near, far, zz;
                         int li = tile * TILE_PTS + wv * 32 + pl;
                         const bool in_range = li < n_loc;
@@ -668,8 +703,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         // entry and kept across the MFMA blocks in scratch (see lane_id above)
                         int Kq = a.job.K;
                         asm volatile("" : "+s"(Kq));
-                        const int lr = a.job.on ? (int)((uint32_t)li / (uint32_t)Kq) : 0;     // ray within the workgroup
-                        if (a.job.from_cam) {
+                        const int lr = flag(a.job.on) ? (int)((uint32_t)li / (uint32_t)Kq) : 0;     // ray within the workgroup
+                        if (flag(a.job.from_cam)) {
                             RayCam cam_q = a.job.cam;
                             asm volatile("" : "+s"(cam_q.W), "+s"(cam_q.fx), "+s"(cam_q.fy));
                             pinhole_ray(cam_q, a.job.pix0 + (int)ray_begin + lr, d);
@@ -680,12 +715,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                             o3[0] = r0.x; o3[1] = r0.y; o3[2] = r0.z;
                             d[0] = r0.w; d[1] = r1.x; d[2] = r1.y; near = r1.z; far = r1.w;
                         }
-                        if (a.job.gen_z) {
+                        if (flag(a.job.gen_z)) {
                             // sample_coarse (nerf.py:98-118), the arithmetic of k_sample_coarse; view pass 0 leaves the positions
                             // in z_out for the compositing, the fine resampling and the caller
                             const int k = li - lr * Kq;
                             const int64_t gp = p_begin + li;
-                            const float u = a.job.noise_c ? a.job.noise_c[gp]
+                            const float u = flagp(a.job.noise_c) ? a.job.noise_c[gp]
                                                           : rng_uniform(a.job.seed, a.job.ray_base + ray_begin + lr, DRAW_COARSE, k);
                             const float t = fmaf(u, 1.0f / (float)Kq, linspace_k(k, Kq));
                             zz = z_from_t(t, near, far, a.job.lindisp);
@@ -738,7 +773,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 uvw[lane] = make_float4(pu[0], pv[0], pu[1], pv[1]);      // for the gather / tap image of this view's blocks
                 STAMP_ACC(1, st_t);
                 lin_in_stages();
-                if (a.job.on && v == 0 && tile > 0) {
+                if (flag(a.job.on) && v == 0 && tile > 0) {
                     // the rays the previous tile finished: every wave has been through the vmcnt(0) and the barriers of the
                     // LIN_IN statement since it stored that tile's outputs, so they are in the L2 for any wave to read
                     int upto = tile * TILE_PTS;
@@ -747,17 +782,21 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     rays_done = upto;
                 }
                 if (a.proj && n_gather == 0) tap_image();          // fully projected: the image serves all blocks of this view
-                else if (!a.proj && n_gather == 1) gather(0);
+                else if (!a.proj && n_gather == 1) gather(0, false);
                 STAMP_ACC(2, st_t);
             }
             for (int b = 0; b < a.nb1; ++b) {
                 // ---- x += lin_z[b](z): all but the block's last part as separate x-stage calls
                 for (int grp = 0; grp < n_groups; ++grp) {
-                    gather(grp);
+                    if (b == 0) gather(grp, true);
+                    else restore(grp);
                     x_stages(8);
                 }
                 if (a.proj && n_gather > 0) tap_image();           // partial projection: the buffer was just used by the gather
-                else if (!a.proj && n_gather > 1) gather(n_gather - 1);
+                else if (!a.proj && n_gather > 1) {
+                    if (b == 0) gather(n_gather - 1, true);
+                    else restore(n_gather - 1);
+                }
                 STAMP_ACC(3, st_t);
                 resblock(b);
                 STAMP_ACC(6, st_t);
@@ -788,7 +827,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             }
             view_pass();
             const int nm1 = a.NS - 1;
-            const float inv = 1.0f / (float)a.NS;
+            int ns_q = a.NS;
+            asm volatile("" : "+s"(ns_q));                  // formed here, not kept from the kernel's entry in scratch
+            const float inv = 1.0f / (float)ns_q;
             const uint32_t lane16 = lane_id() * 16;
             asm volatile(PNR_VIEWREDUCE_ASM : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
                          : PNR_RESBLOCK_CLOBBERS);
@@ -865,10 +906,17 @@ static int num_cus() {
 }
 static constexpr int MAX_GRID = 512;
 
+// 256-channel lin_z groups whose gathered image is kept in the workspace between a view's blocks
+static int cached_groups(const pnr_mlp* mlp, const pnr_views* vw) {
+    if (mlp->packed_texels) return (mlp->d_latent - vw->lat_c[vw->n_levels - 1]) / 256;
+    const int groups = mlp->d_latent / 256;
+    return groups > 1 ? groups : 0;
+}
+static uint64_t spill_bytes(const pnr_views* vw) {
+    return vw->n_views > 1 ? (uint64_t)MAX_GRID * 4 * (vw->n_views - 1) * 4096 * sizeof(float4) : 0;
+}
 uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
-    uint64_t b = 256;
-    if (vw->n_views > 1) b += (uint64_t)MAX_GRID * 4 * (vw->n_views - 1) * 4096 * sizeof(float4);
-    return b;
+    return 256 + spill_bytes(vw) + (uint64_t)MAX_GRID * 4 * cached_groups(mlp, vw) * ZBUF_BYTES;
 }
 
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
@@ -904,6 +952,8 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     for (int i = 0; i < PNR_MAX_LEVELS; ++i) a.lat[i] = (const char*)vw->latent_packed[i];
     a.out = out;
     a.spill = (float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    a.gcache = (char*)a.spill + spill_bytes(vw);
+    a.n_cached = cached_groups(mlp, vw);
     a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
     a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
     a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;

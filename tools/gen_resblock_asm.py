@@ -101,6 +101,8 @@ class Emit:
         assert st == self.reads, ("LDS scoreboard differs between loop entry and back edge", st, self.reads)
 
     def relu_pack(self, dst, a0, a1, tmp):
+        if "nosnap" in DIAG:
+            return
         self.e(f"v_accvgpr_read_b32 v{tmp}, a{a0}")
         self.e(f"v_accvgpr_read_b32 v{tmp + 1}, a{a1}")
         self.relu_pack_v(dst, tmp, tmp + 1)
@@ -148,6 +150,14 @@ class Emit:
         e("s_waitcnt vmcnt(4)")
         e("s_barrier")
         pend = None
+        if "dmaearly" in DIAG:
+            e(f"s_mov_b32 m0, {m0_sreg}")
+            e("s_nop 0")
+            for q in range(4):
+                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+            self.loader_advance()
+        if "dmastagger" in DIAG:
+            e(f"s_mov_b32 m0, {m0_sreg}")
         for f in range(16):
             if f % 4 == 0:
                 self.need([f"A{(f + i) & 7}" for i in range(4)])
@@ -156,12 +166,23 @@ class Emit:
             if pend:
                 self.ds_read(*pend)
             e(m2)
-            if f % 4 == 1:
+            if "dmaearly" in DIAG:
+                pass
+            elif "dmastagger" in DIAG:
+                q, j = f >> 2, f & 3
+                e(f"s_cmp_lg_u32 s30, {j}")
+                e("s_cbranch_scc1 7f")
+                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                e("7:")
+                if f == 15:
+                    self.loader_advance()
+            elif f % 4 == 1:
                 q = f >> 2
                 if q == 0:
                     e(f"s_mov_b32 m0, {m0_sreg}")
                     e("s_nop 0")
-                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                if "dma1" not in DIAG or q == 0:
+                    e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
                 if q == 3:
                     self.loader_advance()
             base = rd_cur if f < 8 else rd_nxt
@@ -190,6 +211,8 @@ def setup_cursor(E, cfg, stream):
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
     e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
+    if "dmastagger" in DIAG:
+        e("s_bfe_u32 s30, %23, 0x2000c")                     # wave index (ring base + wave*4096)
     e("s_mov_b32 s20, %16")
     e("s_mov_b32 s21, %17")
     e("s_mov_b32 s22, %18")
@@ -628,6 +651,10 @@ def main():
                 lines = [("s_waitcnt vmcnt(0)" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
             if "ldswait" in DIAG:
                 lines = [("s_waitcnt lgkmcnt(0)" if l.startswith("s_waitcnt lgkmcnt(") else l) for l in lines]
+            if "dmaplain" in DIAG:      # timing only: ordinary loads into (garbage) registers instead of LDS-DMA
+                lines = [l.replace("global_load_lds_dwordx4 v15,", "global_load_dwordx4 v[68:71], v15,") for l in lines]
+            if "dmaquarter" in DIAG:
+                lines = [l.replace("global_load_lds_dwordx4", "global_load_lds_dword") for l in lines]
             if "nodma" in DIAG:
                 lines = [l for l in lines if not l.startswith("global_load_lds")]
                 lines = [("s_nop 0" if l == "s_waitcnt vmcnt(4)" else l) for l in lines]
