@@ -743,13 +743,13 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         float val[SL];
 #pragma unroll
                         for (int jj = 0; jj < 3 * D; ++jj) {
-                            const int n = 3 * D * g + jj;                    // sine index in code.py's order: 2 D q + D phase + i
-                            const int q = n / (2 * D), rem = n - q * (2 * D);
-                            const int phs = rem >= D ? 1 : 0, i = rem - phs * D;
-                            float vi = i == 0 ? xr[0] : i == 1 ? xr[1] : xr[2];
-                            if (D == 6) vi = i == 3 ? dr[0] : i == 4 ? dr[1] : i == 5 ? dr[2] : vi;
-                            const float fq = __builtin_amdgcn_ldexpf(a.freq_factor, q);
-                            val[jj] = __sinf(fmaf(vi, fq, phs ? 1.57079637f : 0.0f));
+                            // sine n = 3 D g + jj in code.py's order n = 2 D q + D phase + i.  3 D g is a multiple of D, so the
+                            // input i = jj mod D is the same in every lane group (no per-lane select); with m = 3 g + jj / D:
+                            // phase = m & 1, frequency q = m >> 1.
+                            const int i = jj % D, m = 3 * g + jj / D;
+                            const float vi = i < 3 ? xr[i] : dr[i - 3];
+                            const float fq = __builtin_amdgcn_ldexpf(a.freq_factor, m >> 1);
+                            val[jj] = __sinf(fmaf(vi, fq, (m & 1) ? 1.57079637f : 0.0f));
                         }
                         // others: raw input 2 g + o (x_rot 0..2, rotated view dir 3..5) for g < 3; the folded lin_in bias for g = 3
                         const float o0 = g == 0 ? xr[0] : g == 1 ? xr[2] : g == 2 ? dr[1] : 1.0f;
