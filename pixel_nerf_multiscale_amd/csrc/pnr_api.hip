@@ -237,7 +237,8 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         RayJob job{};
         job.on = 1; job.K = Kc; job.gen_z = 1; job.lindisp = params->lindisp; job.white_bkgd = params->white_bkgd;
         job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.ray_base = ray_index_base;
-        job.z_out = zc; job.w_out = w_c; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        job.z_out = zc; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        job.w_out = (Kf > 0 || outputs->coarse_weights) ? w_c : nullptr;      // only the resampling and the caller read them
         if (cam) { job.from_cam = 1; job.cam = *cam; job.pix0 = (int)pix0; }
         PointSrc src{rays, nullptr, Kc, nullptr, nullptr};
         if (outputs->ev_point_begin) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_begin, s));
