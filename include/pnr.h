@@ -246,6 +246,22 @@ int32_t pnr_sample_fine_bwd(const float* rays, const float* depth, int64_t n_ray
                             uint64_t seed, int64_t ray_index_base, const float* z_sorted,
                             const float* d_z_sorted, float* d_depth, void* stream);
 
+/* ResnetFC.forward (model/resnetfc.py:173-236) on rows the caller assembled: zx (n_outer, n_inner_views, n_inner_points,
+ * d_latent + d_in) fp32 with the latent part FIRST; the n_inner_views row blocks are reduced (mean / max, util.py:466-476)
+ * in front of block combine_layer, i.e. combine_inner_dims = (n_inner_views, n_inner_points).  out (n_outer,
+ * n_inner_points, d_out), no activation.  fp32 arithmetic (the 1e-4 parity path); any d_hidden / d_out. */
+uint64_t pnr_resnetfc_workspace_bytes(const pnr_mlp* mlp, int32_t n_inner_views);
+int32_t pnr_resnetfc_forward(const pnr_mlp* mlp, const float* zx, int64_t n_outer, int32_t n_inner_views,
+                             int64_t n_inner_points, float* out, void* workspace, uint64_t workspace_bytes,
+                             void* stream);
+
+/* SpatialEncoder.index (model/encoder.py:138-205): uv (uv_views, n_points, 2) image points -> out (n_objs*n_views, L,
+ * n_points) fp32; bilinear, border padding, align_corners, every level normalised by ITS latent size and concatenated
+ * along the channels.  uv_views = 1 broadcasts one set of points to every view (encoder.py:148-149), else n_objs*n_views.
+ * Reads views->latent[] (fp32 NCHW) and lat_c/h/w only. */
+int32_t pnr_index_latent(const pnr_views* views, const float* uv, int64_t n_points, int32_t uv_views, float* out,
+                         void* stream);
+
 /* pnr_render for the rays of ONE camera, generated inside the render launch (util.gen_rays, util/util.py:118-148,243-281, then
  * NeRFRenderer.forward): ray i is pixel pix0 + i (row-major) of the W x H pinhole image of camera-to-world matrix c2w.
  * What the reference's eval drivers do per frame (eval/eval.py:250-293: gen_rays on the host, H2D, split, render_par per

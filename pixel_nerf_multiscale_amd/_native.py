@@ -92,6 +92,9 @@ PROTOTYPES = {
     "pnr_workspace_bytes": (_u64, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_render": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _i64,
                           _i64, C.POINTER(pnr_noise), _u64, _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),
+    "pnr_resnetfc_workspace_bytes": (_u64, [C.POINTER(pnr_mlp), _i32]),
+    "pnr_resnetfc_forward": (_i32, [C.POINTER(pnr_mlp), _fp, _i64, _i32, _i64, _fp, _fp, _u64, _fp]),
+    "pnr_index_latent": (_i32, [C.POINTER(pnr_views), _fp, _i64, _i32, _fp, _fp]),
     "pnr_render_camera": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_mlp), C.POINTER(pnr_views),
                                  C.POINTER(C.c_float), _i32, _i32, _f, _f, _f, _f, _f, _f, _i64, _i64, C.POINTER(pnr_noise), _u64,
                                  _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),

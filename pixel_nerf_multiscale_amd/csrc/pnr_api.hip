@@ -6,6 +6,10 @@ namespace pnr {
 uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s);
+uint64_t resnetfc_f32_workspace_bytes(const pnr_mlp* mlp, int NS);
+int32_t resnetfc_f32(const pnr_mlp* mlp, const float* zx, int64_t outer, int NS, int64_t B, float* out, void* workspace,
+                     uint64_t ws_bytes, hipStream_t s);
+int32_t index_latent_f32(const pnr_views* vw, const float* uv, int64_t N, int uv_views, float* out, hipStream_t s);
 // stage_kernels.hip
 int32_t sample_fine_launch(const float* rays, float near_all, float far_all, const float* z_coarse, const float* weights,
                            const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
@@ -110,6 +114,49 @@ extern "C" int32_t pnr_point_mlp(const pnr_params* params, const pnr_mlp* mlp, c
     if (!workspace && n_points > 0) return PNR_E_NULL;
     return point_dispatch(params, mlp, views, src, n_points, points_per_obj, out, workspace, workspace_bytes,
                           (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ module-level stage calls (fp32)
+static int32_t check_mlp_f32(const pnr_mlp* mlp) {
+    if (!mlp) return PNR_E_NULL;
+    if (mlp->d_in <= 0 || mlp->d_latent < 0 || mlp->d_hidden <= 0 || mlp->d_out <= 0 || mlp->n_blocks < 0 ||
+        mlp->n_blocks > PNR_MAX_BLOCKS) return PNR_E_SHAPE;
+    if (!mlp->lin_in_w || !mlp->lin_in_b || !mlp->lin_out_w || !mlp->lin_out_b) return PNR_E_NULL;
+    const int n_lin_z = mlp->combine_layer < mlp->n_blocks ? mlp->combine_layer : mlp->n_blocks;
+    for (int b = 0; b < mlp->n_blocks; ++b) {
+        if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
+        if (mlp->d_latent > 0 && b < n_lin_z && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
+    }
+    return PNR_OK;
+}
+
+extern "C" uint64_t pnr_resnetfc_workspace_bytes(const pnr_mlp* mlp, int32_t n_inner_views) {
+    if (!mlp || n_inner_views < 1) return 0;
+    return resnetfc_f32_workspace_bytes(mlp, n_inner_views);
+}
+
+extern "C" int32_t pnr_resnetfc_forward(const pnr_mlp* mlp, const float* zx, int64_t n_outer, int32_t n_inner_views,
+                                        int64_t n_inner_points, float* out, void* workspace, uint64_t workspace_bytes,
+                                        void* stream) {
+    int32_t rc = check_mlp_f32(mlp);
+    if (rc) return rc;
+    if (!zx || !out) return PNR_E_NULL;
+    if (n_outer < 0 || n_inner_views < 1 || n_inner_points < 0) return PNR_E_SHAPE;
+    if (n_outer == 0 || n_inner_points == 0) return PNR_OK;
+    if (!workspace) return PNR_E_NULL;
+    return resnetfc_f32(mlp, zx, n_outer, n_inner_views, n_inner_points, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int32_t pnr_index_latent(const pnr_views* views, const float* uv, int64_t n_points, int32_t uv_views,
+                                    float* out, void* stream) {
+    if (!views || !uv || !out) return PNR_E_NULL;
+    if (views->n_levels < 1 || views->n_levels > PNR_MAX_LEVELS || views->n_objs < 1 || views->n_views < 1) return PNR_E_SHAPE;
+    if (n_points < 0 || (uv_views != 1 && uv_views != views->n_objs * views->n_views)) return PNR_E_SHAPE;
+    for (int i = 0; i < views->n_levels; ++i) {
+        if (!views->latent[i]) return PNR_E_NULL;
+        if (views->lat_c[i] < 1 || views->lat_h[i] < 1 || views->lat_w[i] < 1) return PNR_E_SHAPE;
+    }
+    return index_latent_f32(views, uv, n_points, uv_views, out, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ training entry points (train_f32.hip)

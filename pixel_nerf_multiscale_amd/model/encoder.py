@@ -121,9 +121,32 @@ class SpatialEncoder(nn.Module):
         return m
 
     def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
-        raise RuntimeError(
-            "SpatialEncoder.index is fused into the HIP point kernel (pnr_point_mlp); call "
-            "PixelNeRFNet.forward / NeRFRenderer instead")
+        """uv (B, N, 2) image points -> (B, L, N) pixel-aligned features (reference encoder.py:138-205; bilinear, border
+        padding, align_corners, every level normalised by its own latent size): a native stage call (pnr_index_latent).
+        Inference only; inside the render path the lookup is fused into the point kernels."""
+        import ctypes as C
+        from .. import _native as N
+        maps = self.level_maps()
+        if not uv.is_cuda or not maps[0].is_cuda:
+            raise RuntimeError("SpatialEncoder.index runs on the HIP device only (no CPU / PyTorch evaluation path)")
+        nv = maps[0].shape[0]
+        if uv.dim() != 3 or uv.shape[-1] != 2 or uv.shape[0] not in (1, nv):
+            raise ValueError(f"uv must be (1 or {nv}, N, 2), got {tuple(uv.shape)}")
+        dev = N.same_device(uv, maps[0])
+        v = N.pnr_views()
+        v.n_objs, v.n_views, v.n_levels = nv, 1, len(maps)
+        keep = []
+        for i, mp in enumerate(maps):
+            mp = N.f32c(mp.detach())
+            keep.append(mp)
+            v.latent[i] = N.ptr(mp)
+            v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+        q = N.f32c(uv.detach())
+        n = q.shape[1]
+        out = torch.empty(nv, sum(int(m.shape[1]) for m in maps), n, device=dev)
+        N.check(N.lib.pnr_index_latent(C.byref(v), N.ptr(q), n, int(q.shape[0]), N.ptr(out), N.current_stream(dev)),
+                "pnr_index_latent")
+        return out
 
     @classmethod
     def from_conf(cls, conf, **kwargs):

@@ -678,3 +678,43 @@ def test_rays_generated_inside_the_render_launch_are_bit_identical(name, prec):
         lvl = ref.fine if rend.using_fine else ref.coarse
         assert torch.equal(rgb.reshape(-1, 3), lvl.rgb.reshape(-1, 3)), (W, H)
         assert torch.equal(depth.reshape(-1), lvl.depth.reshape(-1)), (W, H)
+
+
+@pytest.mark.parametrize("name", ["tiny_ns1", "tiny_sb2_ns2", "tiny_max_combine", "full_ns3", "tiny_multiscale_ns2"])
+def test_resnetfc_forward_and_encoder_index_are_native_stage_calls(name):
+    """ResnetFC.forward (resnetfc.py:173-236) and SpatialEncoder.index (encoder.py:138-205) as module calls backed by
+    pnr_resnetfc_forward / pnr_index_latent, against the oracle's restatement of the same two functions: assembled rows
+    with the (views, points) reduction, a flat batch without one, a row count that crosses the 16384-row chunk, and the
+    lookup with per-view and broadcast uv incl. off-image points."""
+    import oracle_util as ou
+    from hip_util import setup
+    from oracle import pixelnerf_oracle as orc
+    fx, spec, net, rend = setup(name)
+    g = torch.Generator().manual_seed(5)
+    mlp = net.mlp_coarse
+    sd = {k: v.detach().cpu() for k, v in mlp.state_dict().items()}
+    SB, NS = spec["SB"], spec["NS"]
+    E = mlp.d_latent + mlp.d_in
+    for P in (7, 16400 if name == "tiny_ns1" else 33):
+        zx = torch.randn(SB * NS * P, E, generator=g)
+        ref = orc.resnetfc(sd, zx, mlp.d_latent, NS, P, n_blocks=mlp.n_blocks, combine_layer=mlp.combine_layer,
+                           combine_type=mlp.combine_type)
+        out = mlp(zx.cuda(), combine_inner_dims=(NS, P))
+        assert tuple(out.shape) == ((SB, P, mlp.d_out) if NS > 1 else (SB * NS * P, mlp.d_out))
+        scale = max(1.0, float(ref.abs().max()))
+        assert maxdiff(out.reshape(-1, mlp.d_out).cpu(), ref) <= 2e-5 * scale, P
+    flat = torch.randn(3, 5, E, generator=g)             # no reduction: leading dims are kept
+    ref = orc.resnetfc(sd, flat.reshape(-1, E), mlp.d_latent, 1, 15, n_blocks=mlp.n_blocks, combine_layer=mlp.combine_layer,
+                       combine_type=mlp.combine_type)
+    out = mlp(flat.cuda())
+    assert tuple(out.shape) == (3, 5, mlp.d_out) and maxdiff(out.reshape(-1, mlp.d_out).cpu(), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # the lookup
+    maps = [m.cpu() for m in net.encoder.level_maps()]
+    nv = maps[0].shape[0]
+    W, H = spec["image"]
+    uv = (torch.rand(nv, 41, 2, generator=g) * 1.4 - 0.2) * torch.tensor([float(maps[-1].shape[3]), float(maps[-1].shape[2])])
+    for q in (uv, uv[:1]):
+        ref = orc.index_latent(q, maps)
+        out = net.encoder.index(q.cuda())
+        assert tuple(out.shape) == tuple(ref.shape)
+        assert maxdiff(out.cpu(), ref) <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -46,6 +46,11 @@ def test_null_and_shape_errors_without_gpu():
     assert N.lib.pnr_sample_coarse(None, 4, 8, 0, None, 0, 0, None, None) == -1
     assert N.lib.pnr_composite(None, None, None, 4, 8, 0, None, None, None, None) == -1
     assert N.lib.pnr_gen_rays(None, 4, 4, 1.0, 1.0, 2.0, 2.0, 0.1, 1.0, 0, 16, None, None) == -1
+    assert N.lib.pnr_resnetfc_forward(None, None, 1, 1, 1, None, None, 0, None) == -1
+    assert N.lib.pnr_resnetfc_workspace_bytes(None, 1) == 0
+    assert N.lib.pnr_index_latent(None, None, 4, 1, None, None) == -1
+    assert N.lib.pnr_render_camera(None, None, None, None, None, 4, 4, 1.0, 1.0, 2.0, 2.0, 0.1, 1.0, 0, 16, None, 0, 0,
+                                   None, None, 0, None) == -1
     with pytest.raises(ValueError):
         N.check(-2, "x")
     with pytest.raises(RuntimeError):
@@ -113,12 +118,18 @@ def test_renderer_surface_and_schedule():
 
 
 def test_container_modules_do_not_evaluate_in_pytorch():
+    """ResnetFC.forward / SpatialEncoder.index are native stage calls: no CPU tensors, no PyTorch evaluation."""
     from pixel_nerf_multiscale_amd.model import ResnetFC, SpatialEncoder
     with pytest.raises(RuntimeError):
         ResnetFC(42, d_latent=8, d_hidden=32)(torch.zeros(2, 50))
+    with pytest.raises(NotImplementedError):
+        ResnetFC(42, d_latent=8, d_hidden=32)(torch.zeros(2, 50), combine_index=torch.zeros(2))
     enc = SpatialEncoder(pretrained=False)
     with pytest.raises(RuntimeError):
-        enc.index(torch.zeros(1, 2, 2))
+        enc.index(torch.zeros(1, 2, 2))          # no latent yet
+    enc(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        enc.index(torch.zeros(1, 2, 2))          # CPU tensors never reach the library
     # the conv trunk itself is ordinary PyTorch (runs once per object, out of the hot path)
     lat = enc(torch.zeros(1, 3, 64, 64))
     assert lat.shape == (1, 256, 4, 4) and enc.latent_size == 256
