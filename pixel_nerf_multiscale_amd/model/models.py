@@ -83,6 +83,7 @@ class PixelNeRFNet(torch.nn.Module):
         # pnr_pack_mlp_projected); off = always the general gather + lin_z kernel path
         self.project_latent = conf.get_bool("project_latent", os.environ.get("PNR_PROJECT_LATENT", "1") != "0")
         self._pack_cache = {}
+        self._struct_cache = {}
         self._ws = None
 
     # ------------------------------------------------------------------ camera setup (backup2:98-150)
@@ -157,7 +158,23 @@ class PixelNeRFNet(torch.nn.Module):
         """pnr_mlp over the module's parameter storage (+ the packed MFMA stream, cached until a
         parameter changes).  With `views` (one object; last latent level 256 channels on <= 256 texels) the stream is the
         projected one (lin_z pre-multiplied with that level's maps, see pnr_pack_mlp_projected) and is also keyed by
-        the latent.  Returns (struct, keepalive)."""
+        the latent.  Returns (struct, keepalive).  The finished struct is cached too, keyed by everything it points at
+        (parameter storages and versions, the projected level), so a steady stream of render calls builds it once."""
+        skey = ("mstruct", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()),
+                self._proj_level_key() if (views is not None and precision != "fp32" and self.project_latent) else None)
+        hit = self._struct_cache.get(skey)
+        if hit is not None:
+            return hit
+        self._struct_cache = {k: v for k, v in self._struct_cache.items() if not (k[0] == "mstruct" and k[1] == id(mlp))}
+        m, keep = self._build_mlp_struct(mlp, precision, views)
+        self._struct_cache[skey] = (m, keep)
+        return m, keep
+
+    def _proj_level_key(self):
+        mp = self.encoder.level_maps()[-1]
+        return (mp.data_ptr(), mp._version, tuple(mp.shape), int(self.num_views_per_obj), len(self.encoder.level_maps()))
+
+    def _build_mlp_struct(self, mlp, precision, views=None):
         m = N.pnr_mlp()
         m.d_in, m.d_latent, m.d_hidden, m.d_out = mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out
         m.n_blocks, m.combine_layer, m.combine_type = mlp.n_blocks, mlp.combine_layer, N.COMBINE[mlp.combine_type]
@@ -204,6 +221,21 @@ class PixelNeRFNet(torch.nn.Module):
         return m, keep
 
     def views_struct(self, precision):
+        """pnr_views over what encode() left on the module (+ the packed 16-bit maps); cached like mlp_struct."""
+        maps = self.encoder.level_maps()
+        maps16 = self.encoder.level_maps16(torch.float16 if precision in ("fp16", "f16") else torch.bfloat16) if precision != "fp32" else None
+        skey = ("vstruct", precision, int(self.num_views_per_obj),
+                tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.poses, self.focal, self.c, *maps)),
+                None if maps16 is None else tuple(m.data_ptr() for m in maps16))
+        hit = self._struct_cache.get(skey)
+        if hit is not None:
+            return hit
+        self._struct_cache = {k: v for k, v in self._struct_cache.items() if k[0] != "vstruct"}
+        out = self._build_views_struct(precision)
+        self._struct_cache[skey] = out
+        return out
+
+    def _build_views_struct(self, precision):
         maps = self.encoder.level_maps()
         dev = maps[0].device
         v, keep = views_from(self.poses, self.focal, self.c, self.num_views_per_obj, maps)

@@ -551,8 +551,8 @@ def gen_linout(dt):
 def gen_viewspill():
     """Park this view's residual stream: the 256 accumulator registers -> workspace slot, float4 index (t*4+q)*64 + lane
     (layout-agnostic: the reduce reads the same registers back).  Operands: %0-%15 x tiles (pinned), %16 slot base (s64),
-    %17 lane*16 (v).  Hazards covered inside: MFMA write -> VMEM read of the AGPR (entry s_nop), store data -> overwrite of
-    the source AGPRs (vmcnt(0) before the statement ends)."""
+    %17 lane*16 (v).  Hazards: MFMA write -> VMEM read of the AGPR (entry s_nop); store data -> overwrite of the source
+    AGPRs is covered by the vmcnt(0) every tile-writing statement opens with."""
     L = []
     e = L.append
     e("s_nop 15")
@@ -563,7 +563,8 @@ def gen_viewspill():
             e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
         e("s_add_u32 s24, s24, 0x1000")
         e("s_addc_u32 s25, s25, 0")
-    e("s_waitcnt vmcnt(0)")
+    # No wait here: the tiles are dead until the next view's LIN_IN statement redefines them, and every statement that
+    # writes them opens with s_waitcnt vmcnt(0) (setup_cursor) — the 64 stores retire behind the next view's prologue.
     return L
 
 
