@@ -84,7 +84,7 @@ static __global__ void __launch_bounds__(256) k_gemm_f32(
 template <bool RELU_X>
 static __global__ void __launch_bounds__(256) k_grad_w_f32(
     const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, float* __restrict__ dW, int ldw,
-    float* __restrict__ db, int M, int N, int K, int rows_per_split) {
+    float* __restrict__ db, int M, int N, int K, int rows_per_split, size_t zs_w, size_t zs_b) {
     __shared__ float Ys[16][64 + 4];
     __shared__ float Xs[16][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -131,9 +131,9 @@ static __global__ void __launch_bounds__(256) k_grad_w_f32(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int k = k0 + tx * 4 + j;
-            if (k < K) atomicAdd(dW + (size_t)n * ldw + k, acc[i][j]);
+            if (k < K) atomicAdd(dW + blockIdx.z * zs_w + (size_t)n * ldw + k, acc[i][j]);
         }
-        if (db && blockIdx.y == 0 && tx == 0) atomicAdd(db + n, bsum[i]);
+        if (db && blockIdx.y == 0 && tx == 0) atomicAdd(db + blockIdx.z * zs_b + n, bsum[i]);
     }
 }
 
@@ -220,7 +220,7 @@ template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
 static __global__ void __launch_bounds__(256) k_mgemm_f32(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
-    int M, int N, int Rn, int r_per_split, int vec_ok) {
+    int M, int N, int Rn, int r_per_split, int vec_ok, size_t zs_c = 0, size_t zs_r = 0) {
     __shared__ float As[2][16][132];
     __shared__ float Bs[2][16][132];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -310,7 +310,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + (size_t)m * ldc + n, v);
+                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -318,7 +318,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
 }
 
 // ------------------------------------------------------------------ bf16 MFMA GEMM on the fp32 tape (opt-in, AMP-like)
@@ -413,7 +413,7 @@ template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
 static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
-    int M, int N, int Rn, int r_per_split) {
+    int M, int N, int Rn, int r_per_split, size_t zs_c = 0, size_t zs_r = 0) {
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -484,7 +484,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + (size_t)m * ldc + n, v);
+                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -492,7 +492,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
 }
 
 // bf16x3: fp32-class products on the bf16 MFMA.  Every operand is split x = hi + lo (two bf16 images in LDS) and a
@@ -503,7 +503,7 @@ template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
 static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
-    int M, int N, int Rn, int r_per_split) {
+    int M, int N, int Rn, int r_per_split, size_t zs_c = 0, size_t zs_r = 0) {
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];      // [hi, lo]
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -571,7 +571,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + (size_t)m * ldc + n, v);
+                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -579,7 +579,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
 }
 
 // dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4): one thread per k
@@ -587,8 +587,11 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
 template <bool RELU_X>
 static __global__ void __launch_bounds__(256) k_grad_w_head(const float4* __restrict__ dY, const float* __restrict__ X,
                                                             int ldx, float* __restrict__ dW, int ldw,
-                                                            float* __restrict__ db, int M, int K, int rows_per_split) {
+                                                            float* __restrict__ db, int M, int K, int rows_per_split,
+                                                            size_t zs_w, size_t zs_b) {
     const int k = blockIdx.x * 256 + threadIdx.x;
+    dW += blockIdx.y * zs_w;
+    if (db) db += blockIdx.y * zs_b;
     const int mb = blockIdx.y * rows_per_split, me = min(M, mb + rows_per_split);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     const bool live = k < K;
@@ -915,9 +918,21 @@ uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
     return carve_tape(mlp, vw, P, nullptr).total;
 }
 
+// Scratch for the weight gradients (carved from the backward workspace): every row split of a dW GEMM writes its own
+// (N, K) slice, the slices are then summed in a fixed order — no fp32 atomics race, so gradients are reproducible.
+struct DetWs { float* part; uint64_t floats; };
+static const int DET_MAX_SPLITS = 32;
+static uint64_t det_ws_floats(const pnr_mlp* mlp) {
+    const uint64_t H = mlp->d_hidden, L = mlp->d_latent, D = mlp->d_in;
+    uint64_t wmax = H * H;
+    if (H * L > wmax) wmax = H * L;
+    if (H * D > wmax) wmax = H * D;
+    return (uint64_t)DET_MAX_SPLITS * (wmax + H);
+}
+
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
     const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;
-    return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + 256;
+    return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + a256(det_ws_floats(mlp) * 4) + 256;
 }
 
 static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
@@ -956,64 +971,104 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
 }
 
 // db (N) += column sums of dY alone: a frozen weight with a trainable bias (needs_input_grad False / True)
-__global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows) {
+__global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows, size_t zs_b) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    db += blockIdx.y * zs_b;
     const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
     float acc = 0.f;
     for (int m = m0; m < m1; ++m) acc += dY[(size_t)m * ldy + n];
     atomicAdd(db + n, acc);
 }
 
-// dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid's z, atomics at the end.
-// Either output may be NULL (a frozen parameter): the GEMM kernels need dW, so a bias-only request takes k_col_sums.
+// Ordered sum of the per-split partials: out[i] += part[0][i] + part[1][i] + ... (fixed order -> run-to-run identical bits)
+__global__ void k_reduce_parts(const float* __restrict__ part, int nz, size_t zs, float* __restrict__ out, int ld, int rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) acc += part[(size_t)z * zs + i];
+    out[(size_t)r * ld + c] += acc;
+}
+
+// dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid, one partial slice per split,
+// ordered reduction at the end.  Either output may be NULL (a frozen parameter): the GEMM kernels need dW, so a bias-only
+// request takes k_col_sums.
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
-                      int N, int K, hipStream_t s, int half = 0) {
+                      int N, int K, hipStream_t s, int half, const DetWs& ws) {
     if ((!dW && !db) || M == 0) return PNR_OK;
+    const size_t zs_w = (size_t)N * K, zs_b = (size_t)N;
+    // rows per split: the kernel's natural slice, enlarged until the splits fit the scratch
+    auto splits_for = [&](int rows, int* rows_out) -> int {
+        int64_t nz = (M + rows - 1) / rows;
+        int64_t cap = (int64_t)(ws.floats / (zs_w + zs_b));
+        if (cap > DET_MAX_SPLITS) cap = DET_MAX_SPLITS;
+        if (cap < 1) cap = 1;
+        if (nz > cap) {
+            int64_t r = (M + cap - 1) / cap;
+            r = (r + rows - 1) / rows * rows;          // keep the kernel's row granularity
+            rows = (int)r;
+            nz = (M + rows - 1) / rows;
+        }
+        *rows_out = rows;
+        return (int)nz;
+    };
+    float* pw = ws.part;                 // (nz, N, K)
+    auto finish = [&](int nz) -> int32_t {
+        float* pb = pw + (size_t)nz * zs_w;
+        if (dW) {
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((zs_w + 255) / 256)), dim3(256), 0, s, pw, nz, zs_w, dW, ldw, N, K);
+            PNR_LAUNCH_CHECK();
+        }
+        if (db) {
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((zs_b + 255) / 256)), dim3(256), 0, s, pb, nz, zs_b, db, N, 1, N);
+            PNR_LAUNCH_CHECK();
+        }
+        return PNR_OK;
+    };
+    if (!ws.part || ws.floats < zs_w + zs_b) return PNR_E_WORKSPACE;
+    int rows, nz;
     if (!dW) {
-        const int rows = 2048;
-        hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)((M + rows - 1) / rows)), dim3(256), 0, s, dY, ldy, db,
-                           (int)M, N, rows);
+        nz = splits_for(2048, &rows);
+        float* pb = pw + (size_t)nz * zs_w;
+        PNR_HIP_CHECK(hipMemsetAsync(pb, 0, (size_t)nz * zs_b * 4, s));
+        hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)nz), dim3(256), 0, s, dY, ldy, pb, (int)M, N, rows, zs_b);
         PNR_LAUNCH_CHECK();
-        return PNR_OK;
+        return finish(nz);
     }
-    if (half && N >= 32 && K >= 32 && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx)) {
-        const int rows = 1024;
-        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));
-        if (half == 3)
-            hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
-                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
-                               N, K, (int)M, rows);
-        else
-            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
-                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
-                               N, K, (int)M, rows);
-        PNR_LAUNCH_CHECK();
-        return PNR_OK;
-    }
-    if (N >= 32 && K >= 32) {
+    const bool mfma_shape = N >= 32 && K >= 32;
+    const bool use_half = half && mfma_shape && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx);
+    const bool head = !mfma_shape && N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0;
+    nz = splits_for(mfma_shape ? 1024 : head ? 256 : 2048, &rows);
+    float* pb = pw + (size_t)nz * zs_w;
+    PNR_HIP_CHECK(hipMemsetAsync(pw, 0, (size_t)nz * (zs_w + zs_b) * 4, s));
+    float* pbk = db ? pb : nullptr;
+    if (mfma_shape) {
         // dW = A B with A(n, r = m) = dY[m][n] and B(r = m, k) = act(X[m][k]): both stored reduction-major
-        const int rows = 1024;
-        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)((M + rows - 1) / rows));
-        hipLaunchKernelGGL((k_mgemm_f32<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
-                           (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, dW, ldw, db,
-                           N, K, (int)M, rows, vec_flags(dY, ldy, X, ldx));
-        PNR_LAUNCH_CHECK();
-        return PNR_OK;
+        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)nz);
+        if (use_half && half == 3)
+            hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
+                               N, K, (int)M, rows, zs_w, zs_b);
+        else if (use_half)
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
+                               N, K, (int)M, rows, zs_w, zs_b);
+        else
+            hipLaunchKernelGGL((k_mgemm_f32<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
+                               N, K, (int)M, rows, vec_flags(dY, ldy, X, ldx), zs_w, zs_b);
+    } else if (head) {
+        dim3 grid((K + 255) / 256, (unsigned)nz);
+        hipLaunchKernelGGL((k_grad_w_head<RELU_X>), grid, dim3(256), 0, s, (const float4*)dY, X, ldx, pw, K, pbk, (int)M, K, rows,
+                           zs_w, zs_b);
+    } else {
+        dim3 grid((N + 63) / 64, (K + 63) / 64, (unsigned)nz);
+        hipLaunchKernelGGL((k_grad_w_f32<RELU_X>), grid, dim3(256), 0, s, dY, ldy, X, ldx, pw, K, pbk, (int)M, N, K, rows, zs_w, zs_b);
     }
-    if (N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0) {
-        const int rows = 256;
-        dim3 grid((K + 255) / 256, (unsigned)((M + rows - 1) / rows));
-        hipLaunchKernelGGL((k_grad_w_head<RELU_X>), grid, dim3(256), 0, s, (const float4*)dY, X, ldx, dW, ldw, db, (int)M, K, rows);
-        PNR_LAUNCH_CHECK();
-        return PNR_OK;
-    }
-    const int rows = 2048;
-    dim3 grid((N + 63) / 64, (K + 63) / 64, (unsigned)((M + rows - 1) / rows));
-    hipLaunchKernelGGL((k_grad_w_f32<RELU_X>), grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, (int)M, N, K, rows);
     PNR_LAUNCH_CHECK();
-    return PNR_OK;
+    return finish(nz);
 }
 
 #define PNR_TRY(expr) do { int32_t _rc = (expr); if (_rc) return _rc; } while (0)
@@ -1081,7 +1136,8 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* dx2 = (float*)wp;               wp += a256((uint64_t)MV * H * 4);
     float* dh = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
     float* dzx = (float*)wp;               wp += a256((uint64_t)MV * E * 4);
-    float* do4 = (float*)wp;
+    float* do4 = (float*)wp;               wp += a256((uint64_t)P * 16);
+    const DetWs dws{(float*)wp, det_ws_floats(mlp)};
     const bool want_p = d_xyz || d_z;
     bool want_lat = false;
     LatGrad lg{};
@@ -1091,17 +1147,17 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     hipLaunchKernelGGL(k_out_act_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (const float4*)out,
                        (const float4*)d_out, P, (float4*)do4);
     PNR_LAUNCH_CHECK();
-    PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s, half)));
+    PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s, half, dws)));
     PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s, half)));
     bool dz_started = false;
     for (int b = nb - 1; b >= 0; --b) {
         const int64_t M = t.rows[b];
-        PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half)));
+        PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws)));
         PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s, half)));
-        PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half)));
+        PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws)));
         PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half)));
         if (L > 0 && b < n_lin_z) {
-            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half)));
+            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half, dws)));
             if (want_dz) {
                 PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
                                            dzx, E, M, L, H, s, half)));
@@ -1116,7 +1172,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
             float* tmp = dx; dx = dx2; dx2 = tmp;
         }
     }
-    PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s, half)));
+    PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s, half, dws)));
     if ((want_p || want_lat) && L > 0 && !dz_started) PNR_HIP_CHECK(hipMemsetAsync(dzx, 0, (size_t)MV * E * 4, s));
     if (want_p)
         PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s, half)));
