@@ -80,7 +80,7 @@ static __global__ void __launch_bounds__(256) k_gemm_f32(
 }
 
 // dW[N,K] += sum_m dY[m,n] act(X[m,k]) over this block's row range; db[n] += sum_m dY[m,n] (k-tile 0 only).
-// 64x64 output tile, 16 rows per step; partial sums land with fp32 atomics (split over M to fill the chip).
+// 64x64 output tile, 16 rows per step; every row split (grid z) stores its partial sums to its own slice (see grad_w).
 template <bool RELU_X>
 static __global__ void __launch_bounds__(256) k_grad_w_f32(
     const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, float* __restrict__ dW, int ldw,
@@ -131,9 +131,9 @@ static __global__ void __launch_bounds__(256) k_grad_w_f32(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int k = k0 + tx * 4 + j;
-            if (k < K) atomicAdd(dW + blockIdx.z * zs_w + (size_t)n * ldw + k, acc[i][j]);
+            if (k < K) dW[blockIdx.z * zs_w + (size_t)n * ldw + k] = acc[i][j];
         }
-        if (db && blockIdx.y == 0 && tx == 0) atomicAdd(db + blockIdx.z * zs_b + n, bsum[i]);
+        if (db && blockIdx.y == 0 && tx == 0) db[blockIdx.z * zs_b + n] = bsum[i];
     }
 }
 
@@ -310,7 +310,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
+                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -318,7 +318,10 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+        else atomicAdd(rowsum + m0 + t, rs);
+    }
 }
 
 // ------------------------------------------------------------------ bf16 MFMA GEMM on the fp32 tape (opt-in, AMP-like)
@@ -484,7 +487,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
+                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -492,7 +495,10 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+        else atomicAdd(rowsum + m0 + t, rs);
+    }
 }
 
 // bf16x3: fp32-class products on the bf16 MFMA.  Every operand is split x = hi + lo (two bf16 images in LDS) and a
@@ -571,7 +577,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
                 if (m >= M) continue;
                 float v = acc[i][j][e] + bn;
                 if (SPLIT) {
-                    atomicAdd(C + blockIdx.z * zs_c + (size_t)m * ldc + n, v);
+                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
                 } else {
                     if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
                     if (R) v += R[(size_t)m * ldr + n];
@@ -579,7 +585,10 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
                 }
             }
         }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) atomicAdd(rowsum + (SPLIT ? blockIdx.z * zs_r : 0) + m0 + t, rs);
+    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+        else atomicAdd(rowsum + m0 + t, rs);
+    }
 }
 
 // dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4): one thread per k
@@ -603,9 +612,9 @@ static __global__ void __launch_bounds__(256) k_grad_w_head(const float4* __rest
         b0 += g.x; b1 += g.y; b2 += g.z; b3 += g.w;
     }
     if (live) {
-        atomicAdd(dW + k, a0); atomicAdd(dW + ldw + k, a1); atomicAdd(dW + 2 * ldw + k, a2); atomicAdd(dW + 3 * ldw + k, a3);
+        dW[k] = a0; dW[ldw + k] = a1; dW[2 * ldw + k] = a2; dW[3 * ldw + k] = a3;
     }
-    if (db && k == 0) { atomicAdd(db, b0); atomicAdd(db + 1, b1); atomicAdd(db + 2, b2); atomicAdd(db + 3, b3); }
+    if (db && k == 0) { db[0] = b0; db[1] = b1; db[2] = b2; db[3] = b3; }
 }
 
 // d(pre-activation) of the output head: rgb = sigmoid(o) -> y(1-y); sigma = relu(o) -> [y > 0]
@@ -921,7 +930,10 @@ uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
 // Scratch for the weight gradients (carved from the backward workspace): every row split of a dW GEMM writes its own
 // (N, K) slice, the slices are then summed in a fixed order — no fp32 atomics race, so gradients are reproducible.
 struct DetWs { float* part; uint64_t floats; };
-static const int DET_MAX_SPLITS = 32;
+#ifndef PNR_DET_MAX_SPLITS
+#define PNR_DET_MAX_SPLITS 64
+#endif
+static const int DET_MAX_SPLITS = PNR_DET_MAX_SPLITS;
 static uint64_t det_ws_floats(const pnr_mlp* mlp) {
     const uint64_t H = mlp->d_hidden, L = mlp->d_latent, D = mlp->d_in;
     uint64_t wmax = H * H;
@@ -978,7 +990,7 @@ __global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restr
     const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
     float acc = 0.f;
     for (int m = m0; m < m1; ++m) acc += dY[(size_t)m * ldy + n];
-    atomicAdd(db + n, acc);
+    db[n] = acc;
 }
 
 // Ordered sum of the per-split partials: out[i] += part[0][i] + part[1][i] + ... (fixed order -> run-to-run identical bits)
@@ -1032,7 +1044,6 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     if (!dW) {
         nz = splits_for(2048, &rows);
         float* pb = pw + (size_t)nz * zs_w;
-        PNR_HIP_CHECK(hipMemsetAsync(pb, 0, (size_t)nz * zs_b * 4, s));
         hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)nz), dim3(256), 0, s, dY, ldy, pb, (int)M, N, rows, zs_b);
         PNR_LAUNCH_CHECK();
         return finish(nz);
@@ -1042,7 +1053,6 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     const bool head = !mfma_shape && N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0;
     nz = splits_for(mfma_shape ? 1024 : head ? 256 : 2048, &rows);
     float* pb = pw + (size_t)nz * zs_w;
-    PNR_HIP_CHECK(hipMemsetAsync(pw, 0, (size_t)nz * (zs_w + zs_b) * 4, s));
     float* pbk = db ? pb : nullptr;
     if (mfma_shape) {
         // dW = A B with A(n, r = m) = dY[m][n] and B(r = m, k) = act(X[m][k]): both stored reduction-major
