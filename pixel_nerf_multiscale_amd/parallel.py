@@ -77,8 +77,15 @@ class ShardedRenderer:
                 pix[: hi - lo, off:off + w] = t.reshape(hi - lo, w)
                 off += w
         if self.world > 1:
-            full = torch.empty(self.world * per, tot, device=rays.device, dtype=torch.float32)
-            dist.all_gather_into_tensor(full, pix, group=self.group)
+            if pix.is_cuda and dist.get_backend(self.group) != "nccl":
+                # a host-memory backend (gloo) under device tensors — rehearsing the multi-rank path with several ranks on
+                # one card, where RCCL refuses duplicate devices: the (small) message travels through the host
+                host = torch.empty(self.world * per, tot, dtype=torch.float32)
+                dist.all_gather_into_tensor(host, pix.cpu(), group=self.group)
+                full = host.to(rays.device)
+            else:
+                full = torch.empty(self.world * per, tot, device=rays.device, dtype=torch.float32)
+                dist.all_gather_into_tensor(full, pix, group=self.group)
         else:
             full = pix
         full = full[:B]

@@ -1,0 +1,66 @@
+"""The multi-rank render path on the real HIP renderer (SURVEY §8 e, a16): two ranks, one process each, BOTH on cuda:0
+(the GPU box has one card and RCCL refuses duplicate devices, so the process group is gloo and the gathered message
+travels through the host — everything else is the production path: NeRFRenderer.bind_parallel under an initialised
+process group, parallel.ShardedRenderer, per-rank ray ranges, noise keyed by the global ray index).  The frame every rank
+returns must equal the unsharded render bit for bit.  Runs first (file name) because the workers have to be started
+before this process initialises the GPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, prec, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import golden_util as gu
+        from hip_util import setup
+        from pixel_nerf_multiscale_amd.parallel import frame_seed
+        fx, spec, net, rend = setup(name, precision=prec)
+        rend.fixed_noise = None
+        W, H = spec["image"]
+        g = torch.Generator().manual_seed(11)
+        tgt = gu.pose_spherical(65.0, -25.0, spec["radius"])
+        pix = torch.randperm(W * H, generator=g)[:1001].numpy()                      # odd count: ragged last shard
+        rays = torch.from_numpy(gu.pinhole_rays(tgt, W, H, spec["focal"], spec["z_near"], spec["z_far"], pix))[None].cuda()
+        render_par = rend.bind_parallel(net, [0, 1], simple_output=True).eval()      # the call site of eval/eval.py:151
+        assert type(render_par).__name__ == "_ShardedRenderWrapper"
+        rgb, depth = render_par(rays)                                                # eval/eval.py:280
+        rend.forced_seed = frame_seed(render_par.sharded.base_seed, 0)               # the same frame on one rank
+        ref = rend(net, rays)
+        lvl = ref.fine if rend.using_fine else ref.coarse
+        ok = bool(torch.equal(rgb, lvl.rgb)) and bool(torch.equal(depth, lvl.depth))
+        q.put((rank, ok, float(rgb.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,prec", [("full_ns1", "bf16"), ("full_dtu_ns3", "fp16")])
+def test_two_ranks_on_one_card_return_the_unsharded_frame(name, prec):
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has already initialised the GPU; worker processes must be started before that")
+    import torch.multiprocessing as mp
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    os.environ["PYTHONPATH"] = os.pathsep.join([p for p in sys.path if p])           # tests/ and the repo root for the workers
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, prec, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0
