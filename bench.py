@@ -178,7 +178,7 @@ def time_workload(workload, precision, device, steps, warmup, world=1, scaling="
     dt = time.perf_counter() - t0
     rend.point_events = None
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kms = []
@@ -269,12 +269,20 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PNR_BENCH_ONE_CARD=1: rehearsal of the N-rank path on a box with ONE card — every rank on cuda:0, gloo instead of
+    # RCCL (which refuses duplicate devices).  Exercises the launcher, the sharding and the timing protocol; the numbers
+    # mean nothing and the line says so ("rehearsal").
+    one_card = world > 1 and os.environ.get("PNR_BENCH_ONE_CARD") == "1"
+    dev_index = 0 if one_card else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_card:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     scaling = args.scaling if args.scaling != "auto" else ("strong" if args.workload.startswith("dtu") else "weak")
 
     rec, (spec, net, rend, rays) = time_workload(args.workload, args.precision, device, args.steps, args.warmup, world,
@@ -292,6 +300,8 @@ def main():
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
         "config": rec["config"], "roofline": rec["roofline"],
     }
+    if one_card:
+        out["rehearsal"] = f"{world} ranks on ONE card over gloo (PNR_BENCH_ONE_CARD=1): protocol check, not a measurement"
     if rank == 0 and world == 1 and args.cpu_rays > 0:
         v, cdt, res, idx, noise = cpu_baseline(spec, args.cpu_rays, rays)
         out["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
