@@ -520,6 +520,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     const int p_steps = a.proj ? a.SZ - 8 * a.Gg : 0;     // texel k-steps of the projected last level
     // the last lin_z call of a block (a gathered group, or the projected part) runs as the prefix of the resblock asm
     const int n_groups = a.proj ? n_gather : n_gather - 1;  // gathered groups that go through separate x_stages calls
+    const bool one_part = n_groups == 0;                    // a block has ONE lin_z part: its B image is written once per view
     // ---------------- compositing of this workgroup's finished rays (fused render launch): ray lr of the workgroup by wave
     // lr & 3, from what the waves stored to `out` (and z_out) — through the L2: see ld_f in pnr_common.h
     auto composite_rays = [&](int lr0, int lr1) __attribute__((always_inline)) {
@@ -663,10 +664,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                              : PNR_RESBLOCK_CLOBBERS);
         };
         // ---- resblock b: [last lin_z part] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62, 203-234)
-        auto resblock = [&](int b) __attribute__((always_inline)) {
+        // n_pre consecutive blocks from b on with the lin_z prefix, then n_plain without, in ONE statement (its block loop)
+        auto resblocks = [&](int b, int n_pre, int n_plain) __attribute__((always_inline)) {
+            if (n_pre + n_plain == 0) return;
             PNR_LANE_OPERANDS;
             const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + (ln_ >> 4) * 16;
-            const int cfg2z = (b < a.nb1) ? (a.proj ? p_steps : 8) : 0;       // lin_z prefix: k-steps of the last part
+            const int cfg2z = (a.proj ? p_steps : 8) | (n_pre << 16) | (n_plain << 20);   // k-steps of the prefix (last lin_z part)
             if (DT == PNR_BF16)
                 asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
                              : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
@@ -785,7 +788,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 else if (!a.proj && n_gather == 1) gather(0, false);
                 STAMP_ACC(2, st_t);
             }
-            for (int b = 0; b < a.nb1; ++b) {
+            // One lin_z part per block (one_part): the B image written above serves every block of the view, so they run in ONE
+            // statement (single view: the blocks behind the reduction follow in it too).  The same loop and the same
+            // statement serve both cases — a second call site would make hipcc merge the tiles from two paths (through scratch).
+            const int b_step = one_part ? a.nb1 : 1;
+            const int plain_here = (one_part && !MULTIVIEW) ? a.n_blocks - a.nb1 : 0;
+            for (int b = 0; b < a.nb1; b += b_step) {
                 // ---- x += lin_z[b](z): all but the block's last part as separate x-stage calls
                 for (int grp = 0; grp < n_groups; ++grp) {
                     if (b == 0) gather(grp, true);
@@ -798,7 +806,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     else restore(n_gather - 1);
                 }
                 STAMP_ACC(3, st_t);
-                resblock(b);
+                resblocks(b, b_step, plain_here);
                 STAMP_ACC(6, st_t);
             }
         };
@@ -839,8 +847,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #undef PNR_X_TILES
 #undef PNR_X_TILES_IN
         // ---- the blocks after the view reduction
-        for (int b = a.nb1; b < a.n_blocks; ++b) {
-            resblock(b);
+        for (int i = (MULTIVIEW || !one_part) ? 0 : 1; i < 1; ++i) {       // a loop, not an `if`: see view_pass
+            resblocks(a.nb1, 0, a.n_blocks - a.nb1);
             STAMP_ACC(6, st_t);
         }
 

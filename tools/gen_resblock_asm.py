@@ -156,8 +156,6 @@ class Emit:
             for q in range(4):
                 e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
             self.loader_advance()
-        if "dmastagger" in DIAG:
-            e(f"s_mov_b32 m0, {m0_sreg}")
         for f in range(16):
             if f % 4 == 0:
                 self.need([f"A{(f + i) & 7}" for i in range(4)])
@@ -168,14 +166,6 @@ class Emit:
             e(m2)
             if "dmaearly" in DIAG:
                 pass
-            elif "dmastagger" in DIAG:
-                q, j = f >> 2, f & 3
-                e(f"s_cmp_lg_u32 s30, {j}")
-                e("s_cbranch_scc1 7f")
-                e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-                e("7:")
-                if f == 15:
-                    self.loader_advance()
             elif f % 4 == 1:
                 q = f >> 2
                 if q == 0:
@@ -211,8 +201,6 @@ def setup_cursor(E, cfg, stream):
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
     e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
-    if "dmastagger" in DIAG:
-        e("s_bfe_u32 s30, %23, 0x2000c")                     # wave index (ring base + wave*4096)
     e("s_mov_b32 s20, %16")
     e("s_mov_b32 s21, %17")
     e("s_mov_b32 s22, %18")
@@ -392,7 +380,9 @@ def snapshot_hooks(E, ks0):
 def gen(dt):
     """One resblock.  Inputs after the common %0-%20: %21 cfg, %22 stream (s64), %23 ring + wave*4096 (s), %24 ring +
     lane*16 (v), %25 DMA lane offset (v), %26 LDS address of fc_0.bias[block] + 16*(lane>>4) (v), %27 bias B dword 0 (v),
-    %28 lin_z B image address + lane*16 (v), %29 lin_z cfg2 = k-steps (0 = none; the bias k-step is always part of the block).
+    %28 lin_z B image address + lane*16 (v), %29 = lin_z k-steps of a prefixed block | number of consecutive blocks with the
+    lin_z prefix << 16 | number of blocks without it after them << 20 (%26 names the FIRST block's bias rows; the bias k-step
+    is always part of a block).
     Stage order (k_pack_mlp follows it): [lin_z k-steps x 2] | bias x 2 | F(0) | F(1) G(0) | ... | F(15) G(14) | G(15), with
     F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[32c..32c+31, :] . relu(x)) and G(c) = its 2 fc_1 stages
     (x += W1[:, 32c..32c+31] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
@@ -410,15 +400,26 @@ def gen(dt):
     if "barA" in DIAG:
         e("s_waitcnt vmcnt(4)")
         e("s_barrier")
-    e("s_cmp_eq_u32 %29, 0")
+    # Block loop: %29 = lin_z k-steps | blocks WITH the lin_z prefix << 16 | blocks without << 20.  Consecutive blocks of a
+    # tile run inside ONE statement when nothing has to happen between them (one lin_z part per block: the B image in LDS
+    # serves them all) — a statement boundary costs ~700 cycles (drains, cursor set-up, the first fragments' LDS latency).
+    e("s_bfe_u32 s30, %29, 0x40010")                         # offset 16, width 4
+    e("s_bfe_u32 s31, %29, 0x40014")                         # offset 20, width 4
+    e("s_mov_b32 s33, 0")                                    # byte offset of the block's fc_0.bias rows from %26
+    E.loop_begin("8")
+    e("s_cmp_eq_u32 s30, 0")
     e("s_cbranch_scc1 5f")
     xstages_core(E, "%28", "%29", "%24", "%23", "%25", "%27")
-    E.drain()                                                # both paths reach 5: with nothing in flight
+    E.drain()                                                # both paths reach 9: with nothing in flight
+    e("s_sub_u32 s30, s30, 1")
+    e("s_branch 9f")
     e("5:")
+    e("s_sub_u32 s31, s31, 1")
+    e("9:")
     if "drainB" in DIAG:
         e("s_waitcnt vmcnt(0)")
     fixed_bases(E, "%24", "%23")
-    e("v_mov_b32 v14, %26")
+    e("v_add_u32 v14, s33, %26")
     e("v_mov_b32 v15, %25")
     e("v_mov_b32 v16, %27")
     for i in range(1, 8):
@@ -505,11 +506,21 @@ def gen(dt):
         src = ACC[1] + 8 * rgl + 4 * cg + 2 * p
         E.relu_pack_v(60 + 4 * cg + 2 * rgl + p, src, src + 1)
     G(64)
-    # ---------------------------------------------------------------- exit: 2 bias + 64 chunk stages consumed
+    # ---------------------------------------------------------------- block end: 2 bias + 64 chunk stages consumed
     E.drain()
+    e("s_add_u32 s20, s20, 66")
+    e("s_and_b32 s20, s20, 3")
+    e("s_add_u32 s22, s22, 66")
+    e("s_and_b32 s22, s22, 3")
+    e("s_add_u32 s33, s33, 0x800")                           # next block's bias rows (512 floats)
+    e("s_nop 7")                                             # the last MFMAs of the block have read their B registers
+    e("s_or_b32 s35, s30, s31")
+    e("s_cmp_lg_u32 s35, 0")
+    e("s_cbranch_scc1 8b")
+    E.loop_end()
     e("s_nop 15")
     e("s_nop 15")
-    exit_cursor(E, 66)
+    exit_cursor(E, 0)
     return E.L
 
 
