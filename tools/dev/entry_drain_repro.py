@@ -1,4 +1,5 @@
-"""Debug (GPU box): rays mode (renderer) determinism + parity, fp16/bf16 vs fp32 path."""
+"""Diagnostic (GPU box): run-to-run determinism and parity of the fp16 / bf16 kernels vs the fp32 path in rays mode — the script
+behind the statement-entry drain evidence of DESIGN.md §4.1 (build the variants with tools/dev/build_variant.sh NAME "drainA" ...)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -191,7 +191,7 @@ def setup_cursor(E, cfg, stream):
     # hipcc may have a scalar (kernel-argument) load or an LDS access of its own in flight when the statement starts: both
     # count in lgkmcnt, SMEM returns out of order, and every wait below is a COUNTED lgkmcnt(N) — drain them first
     e("s_waitcnt lgkmcnt(0)")
-    # ... and start with no LDS-DMA piece of the previous statement in flight.  Measured (tools/dev/dbg_prec6.py, fp16 build,
+    # ... and start with no LDS-DMA piece of the previous statement in flight.  Measured (tools/dev/entry_drain_repro.py, fp16 build,
     # 3 .. 250 workgroups): without this wait a statement that OPENS with x-stages while the previous statement's last two
     # stages of pieces are still landing returns run-to-run different results (30 dB); vmcnt(0) here, or a 256-cycle
     # s_sleep, makes them exact and repeatable, while vmcnt(4), a barrier, vmcnt(0) / lgkmcnt(0) at every stage INSIDE the
