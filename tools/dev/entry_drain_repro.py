@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): run-to-run determinism and parity of the fp16 / bf16 kernels vs the fp32 path in rays mode — the script
-behind the statement-entry drain evidence of DESIGN.md §4.1 (build the variants with tools/dev/build_variant.sh NAME "drainA" ...)."""
+behind the statement-entry drain evidence of DESIGN.md §4.1 (tools/dev/build_variant.sh bad "noentrydrain" builds the failing library, ... bad_a "noentrydrain drainA" the
+repaired one; run with PNR_LIB=tools/dev/libpnr_<NAME>.so)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
