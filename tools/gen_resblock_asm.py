@@ -197,7 +197,7 @@ def setup_cursor(E, cfg, stream):
     # s_sleep, makes them exact and repeatable, while vmcnt(4), a barrier, vmcnt(0) / lgkmcnt(0) at every stage INSIDE the
     # statements, or a drain behind the x-stages do not.  It costs 0.1 % (the pieces are two stages old).  The mechanism is
     # not identified; DESIGN.md §8 lists what was ruled out.
-    if "noentrydrain" not in DIAG:                          # PNR_ASM_DIAG=noentrydrain reproduces the fp16 failure
+    if "noentrydrain" not in DIAG:                          # PNR_ASM_DIAG=noentrydrain: the build WITHOUT this wait
         e("s_waitcnt vmcnt(0)")
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
