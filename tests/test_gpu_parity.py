@@ -718,3 +718,51 @@ def test_resnetfc_forward_and_encoder_index_are_native_stage_calls(name):
         out = net.encoder.index(q.cuda())
         assert tuple(out.shape) == tuple(ref.shape)
         assert maxdiff(out.cpu(), ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Kc,Kf,Kfd,n_rays", [(150, 100, 30, 5), (1, 0, 0, 131), (37, 11, 11, 131), (128, 64, 0, 3), (300, 212, 100, 2)])
+@pytest.mark.parametrize("name,prec", [("full_ns1", "bf16"), ("full_ns3", "fp16")])
+def test_fused_render_launch_ragged_sample_counts(name, prec, Kc, Kf, Kfd, n_rays):
+    """The fused launch against the staged launches where rays do not line up with the 128-point tiles: rays longer than a
+    tile (a ray is finished — and composited — several tiles after it started), one sample per ray, sample counts that are
+    not multiples of anything, fewer rays than workgroups; in-kernel noise.  Bit-identical pixels, depths, weights, positions."""
+    from hip_util import setup
+    fx, spec, net, rend = setup(name, precision=prec)
+    rend.fixed_noise = None
+    rend.forced_seed = 777
+    rend.keep_samples = True
+    rend.n_coarse, rend.n_fine, rend.n_fine_depth = Kc, Kf, Kfd
+    rend.using_fine = Kf > 0
+    W, H = spec["image"]
+    g = torch.Generator().manual_seed(Kc * 7 + n_rays)
+    tgt = gu.pose_spherical(50.0, -20.0, spec["radius"])
+    pix = torch.randperm(W * H, generator=g)[:n_rays].numpy()
+    rays = torch.from_numpy(gu.pinhole_rays(tgt, W, H, spec["focal"], spec["z_near"], spec["z_far"], pix))[None].cuda()
+    fused = rend(net, rays, want_weights=True)
+    staged = _staged_render(net, rend, rays)
+    for lvl, (w, rgb, depth, z) in staged.items():
+        assert torch.equal(fused[lvl].z.reshape(n_rays, -1), z), (lvl, "z")
+        assert torch.equal(fused[lvl].weights.reshape(n_rays, -1), w), (lvl, "weights")
+        assert torch.equal(fused[lvl].rgb.reshape(n_rays, 3), rgb), (lvl, "rgb")
+        assert torch.equal(fused[lvl].depth.reshape(n_rays), depth), (lvl, "depth")
+
+
+@pytest.mark.parametrize("NS,SB,N", [(2, 2, 333), (1, 3, 50), (3, 2, 129)])
+def test_fused_render_launch_several_objects(NS, SB, N):
+    """Several objects per call (SB > 1): a workgroup's ray range may cross from one object to the next inside a tile, every
+    point picking its own object's cameras and latents.  Fused launch == staged launches, bit for bit (bf16)."""
+    from hip_util import build_net, build_renderer
+    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=N, seed=90 + NS + SB)
+    rays_np, poses = gu.make_inputs(spec)
+    rays = torch.from_numpy(rays_np).cuda()
+    net = build_net(spec, poses, "cuda", "bf16")
+    rend = build_renderer(spec)
+    rend.forced_seed = 17
+    rend.keep_samples = True
+    fused = rend(net, rays, want_weights=True)
+    staged = _staged_render(net, rend, rays)
+    for lvl, (w, rgb, depth, z) in staged.items():
+        assert torch.equal(fused[lvl].z.reshape(SB * N, -1), z), (lvl, "z")
+        assert torch.equal(fused[lvl].weights.reshape(SB * N, -1), w), (lvl, "weights")
+        assert torch.equal(fused[lvl].rgb.reshape(SB * N, 3), rgb), (lvl, "rgb")
+        assert torch.equal(fused[lvl].depth.reshape(SB * N), depth), (lvl, "depth")
