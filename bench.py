@@ -207,6 +207,11 @@ def time_workload(workload, precision, device, steps, warmup, world=1, scaling="
                      # is what `achieved` is priced on; frac_executed prices the executed ones
                      "executed_flops_per_launch": flops_launch * executed_ratio(spec, net),
                      "frac_executed": achieved / peak * executed_ratio(spec, net)},
+        # SURVEY §8d asks for the HBM figure alongside: algorithmic bytes of the fused launch are 48 B/ray (ray in, pixel out)
+        # plus the frame constants; by design the launch also writes and re-reads rgb-sigma and z once (16 + 4 B per point,
+        # L2-resident).  Against 8 TB/s this is ~0: the launch is judged on the MFMA fraction.
+        "hbm": {"algorithmic_bytes_per_ray": 48, "bytes_per_launch_incl_round_trip": rays_rank0 * (48 + 2 * 20 * spec["Kc"]),
+                "achieved_GBps": rays_rank0 * (48 + 2 * 20 * spec["Kc"]) / (k_ms * 1e-3) / 1e9, "peak_GBps": 8000.0},
     }
     return rec, (spec, net, rend, rays)
 
@@ -298,7 +303,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
-        "config": rec["config"], "roofline": rec["roofline"],
+        "config": rec["config"], "roofline": rec["roofline"], "hbm": rec["hbm"],
     }
     if one_card:
         out["rehearsal"] = f"{world} ranks on ONE card over gloo (PNR_BENCH_ONE_CARD=1): protocol check, not a measurement"
