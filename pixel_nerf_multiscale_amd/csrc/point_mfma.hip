@@ -11,13 +11,20 @@
 //   * the weights of the whole MLP are pre-packed (pnr_pack_mlp) into a linear stream of 1-KiB MFMA A-fragments
 //     (16 rows x 32 k) in exactly the order the kernel consumes them; every fragment feeds TWO MFMAs (the two column
 //     groups).  All 4 waves consume the same stream, staged through a 4-slot x 16-KiB LDS ring filled by LDS-DMA
-//     (global_load_lds_dwordx4) two stages ahead, one barrier per stage of 32 MFMAs.  Every workgroup streams the same
+//     (global_load_lds_dwordx4) three stages ahead, one barrier per stage of 32 MFMAs.  Every workgroup streams the same
 //     bytes in the same order => L2-resident across the XCD.
 //   * every MFMA is issued from the hand-scheduled asm blocks of resblock_asm.inc (tools/gen_resblock_asm.py); this
 //     file holds the packers, the per-tile prologue (geometry, positional features, latent gather / tap weights into
 //     the wave's LDS B-operand image) and the epilogue.
 //   * multi-view: the first `combine_layer` blocks run once per source view on the same 128 points; the per-view
 //     residual streams are parked in a caller-provided workspace and reduced (mean/max) in registers.
+//   * render launch (RayJob, pnr_render / pnr_render_camera): workgroups own whole rays; rays come from the ray tensor or are
+//     formed from a camera and the pixel index, coarse sample positions are generated in the tile prologue, and the rays a
+//     tile finished are composited (composite_ray, pnr_common.h) by their workgroup at the start of the next tile — one
+//     launch per pass, bit-identical to the stage kernels (NeRFRenderer.forward, render/nerf.py:98-118,176-249,251-303).
+//   * nothing per-lane stays live across the asm blocks: lane index, divisors and launch-uniform switches are re-derived
+//     through opaque copies at their uses (a value hipcc keeps across a block comes back through scratch, behind a
+//     vmcnt(0) that also drains the run-ahead LDS-DMA).
 #include <type_traits>
 
 #include "pnr_common.h"

@@ -4,14 +4,15 @@ Generates pixel_nerf_multiscale_amd/csrc/resblock_asm.inc: the hand-scheduled gf
 kernel (csrc/point_mfma.hip) — every MFMA of the network is issued from here:
 
   PNR_XSTAGES_ASM_{BF16,F16}    n k-steps 'x += W . B' with B = a k-step image in the wave's LDS buffer (LIN_IN, lin_z)
-  PNR_RESBLOCK_ASM_{BF16,F16}   one block: [lin_z k-steps] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62)
+  PNR_RESBLOCK_ASM_{BF16,F16}   a RUN of blocks, each [lin_z k-steps] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62)
   PNR_LINOUT_ASM_{BF16,F16}     last fc_1 bias + lin_out(relu(x))                                           (resnetfc.py:235)
   PNR_VIEWSPILL_ASM / PNR_VIEWREDUCE_ASM   park / reduce the per-view residual streams                       (util.py:466-476)
 
 MFMA shape: v_mfma_f32_16x16x32_{bf16,f16}, TWO per 1-KiB weight fragment (the wave's 32 points = two 16-column
 groups).  Same LDS bytes, same MFMA cycles per FLOP as one 32x32x16 per fragment, but the chip holds a ~15 % higher
 clock on this shape under the kernel's load (tools/dev/ubench/shape_ubench.hip: 1.92-1.96 vs 1.66-1.69 GHz, 11 %
-less wall time per chunk; MI355X_MICROARCH.md 'DVFS give-back' item 7).
+less wall time per chunk; MI355X_MICROARCH.md 'DVFS give-back' item 7).  The kernel is limited by board power, not by a
+pipe: PNR_ASM_DIAG builds without the weight DMA run 12 % faster but only 4 % fewer cycles.
 
 Data layout (shared with k_pack_mlp and the kernel prologue, point_mfma.hip):
   * lane l: c = l & 15 (column), g = l >> 4 (k-quarter).  The wave's points are (cg, c), cg = 0, 1.
@@ -36,7 +37,9 @@ s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
 import os
 import re
 
-DIAG = os.environ.get("PNR_ASM_DIAG", "")      # timing experiments only: 'nobarrier', 'nodma', 'nowait' (results are garbage)
+# timing experiments only (results are garbage): nobarrier, nodma, nowait, nosnap, dma1, dmaearly, dmaplain, dmaquarter;
+# hazard experiments: fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA, noentrydrain
+DIAG = os.environ.get("PNR_ASM_DIAG", "")
 
 
 def A(i):
