@@ -704,7 +704,14 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     const Cam cam = a.vw.n_objs == 1 ? load_cam(a.vw, __builtin_amdgcn_readfirstlane(v)) : load_cam(a.vw, view_of(c, cg, v));
                     float p[3], d[3], xr[3], dr[3];
                     const int pl = 16 * cg + c;
-                    if ((flag(a.job.from_cam) || flagp(a.src.rays))) {
+                    // several views: the point and its direction do not depend on the view — view pass 0 leaves them in the
+                    // wave's tile-input buffer (over the ray records it has consumed) and the later passes read them back
+                    // instead of repeating ray / sample arithmetic (Philox, divisions)
+                    if (MULTIVIEW && v > 0 && (flag(a.job.from_cam) || flagp(a.src.rays))) {
+                        const float4 cp = *(const float4*)(pts + pl * 16), cd = *(const float4*)(pts + 512 + pl * 16);
+                        p[0] = cp.x; p[1] = cp.y; p[2] = cp.z;
+                        d[0] = cd.x; d[1] = cd.y; d[2] = cd.z;
+                    } else if ((flag(a.job.from_cam) || flagp(a.src.rays))) {
                         float o3[3], near, far, zz;
                         int li = tile * TILE_PTS + wv * 32 + pl;
                         const bool in_range = li < n_loc;
@@ -739,6 +746,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                             zz = *(const float*)(pts + 1024 + pl * 4);
                         }
                         p[0] = fmaf(zz, d[0], o3[0]); p[1] = fmaf(zz, d[1], o3[1]); p[2] = fmaf(zz, d[2], o3[2]);
+                        if (MULTIVIEW && g == 0) {        // every lane of the wave has read its ray record above (program order)
+                            *(float4*)(pts + pl * 16) = make_float4(p[0], p[1], p[2], zz);
+                            *(float4*)(pts + 512 + pl * 16) = make_float4(d[0], d[1], d[2], 0.f);
+                        }
                     } else {
                         const float* q3 = (const float*)(pts + pl * 4);
                         p[0] = q3[0]; p[1] = q3[64]; p[2] = q3[128];
