@@ -53,7 +53,7 @@ typedef struct pnr_mlp {
     int32_t n_blocks;            /* 5 */
     int32_t combine_layer;       /* 3: views are reduced before this block; lin_z exists for b < min(combine_layer, n_blocks) */
     int32_t combine_type;        /* PNR_COMBINE_* */
-    int32_t reserved0;
+    int32_t packed_objs;         /* projected streams only: number of objects `packed` holds a stream for (0 = 1) */
     const float* lin_in_w;  const float* lin_in_b;
     const float* lin_z_w[PNR_MAX_BLOCKS];  const float* lin_z_b[PNR_MAX_BLOCKS];
     const float* fc0_w[PNR_MAX_BLOCKS];    const float* fc0_b[PNR_MAX_BLOCKS];
@@ -140,14 +140,16 @@ const char* pnr_error_string(int32_t code);
  * (bf16 or fp16; biases folded in).  `out` must hold pnr_packed_mlp_bytes() bytes, 16-B aligned. */
 uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp);
 int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_bytes, void* stream);
-/* Projected stream: for ONE object (views->n_objs == 1, 1..8 source views) whose LAST latent level has 256 channels on
+/* Projected stream: for 1..16 objects (1..8 source views each) whose LAST latent level has 256 channels on
  * 4 <= Hl*Wl <= 256 texels (single-scale SRN / NMR maps; the coarsest level of the multi-scale encoder — the levels
  * before it, whole 256-channel groups, are still gathered) bilinear lookup and lin_z are both linear, so
  * lin_z_b(index(uv)) = (W_z,b . Lat) . w(uv) with w the point's 4 tap weights spread over the Hl*Wl texels.  The
  * stream then carries W_z,b . Lat (512 x Hl*Wl) in place of W_z,b (512 x d_latent) and the kernel needs no latent
  * gather; with several views the per-view part of the stream is laid out once per view, each copy with its own
- * view's product.  Re-pack whenever the weights OR the latent maps change; pnr_packed_mlp_projected_bytes() returns 0 when
- * the shapes do not qualify.  Set pnr_mlp.packed_texels = Hl*Wl on the struct that carries this stream. */
+ * view's product; with several objects the blob holds one such stream per object and the kernels assign their workgroups
+ * per object.  Re-pack whenever the weights OR the latent maps change; pnr_packed_mlp_projected_bytes() returns 0 when
+ * the shapes do not qualify.  Set pnr_mlp.packed_texels = Hl*Wl and pnr_mlp.packed_objs = views->n_objs on the struct that
+ * carries this stream; it is refused (PNR_E_PACKED) for any other object count or map size. */
 uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr_views* views);
 int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,
                                uint64_t out_bytes, void* stream);

@@ -24,7 +24,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 class pnr_mlp(C.Structure):
     _fields_ = [
         ("d_in", C.c_int32), ("d_latent", C.c_int32), ("d_hidden", C.c_int32), ("d_out", C.c_int32),
-        ("n_blocks", C.c_int32), ("combine_layer", C.c_int32), ("combine_type", C.c_int32), ("reserved0", C.c_int32),
+        ("n_blocks", C.c_int32), ("combine_layer", C.c_int32), ("combine_type", C.c_int32), ("packed_objs", C.c_int32),
         ("lin_in_w", _fp), ("lin_in_b", _fp),
         ("lin_z_w", _fp * PNR_MAX_BLOCKS), ("lin_z_b", _fp * PNR_MAX_BLOCKS),
         ("fc0_w", _fp * PNR_MAX_BLOCKS), ("fc0_b", _fp * PNR_MAX_BLOCKS),

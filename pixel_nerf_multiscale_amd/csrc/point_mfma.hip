@@ -157,7 +157,7 @@ __global__ void k_project_latent(pnr_mlp m, Layout y, const float* __restrict__ 
 }
 
 template <int DT>
-__global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const float* __restrict__ M) {
+__global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const float* __restrict__ M, uint64_t stream_off = 0) {
     // bias table (fc_0 biases: chunk-accumulator init; lin_out bias: epilogue)
     float* bt = (float*)out;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < y.btab_floats; i += gridDim.x * blockDim.x) {
@@ -166,7 +166,7 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
         else if (i < m.n_blocks * HID + 4) v = m.lin_out_b[i - m.n_blocks * HID];
         bt[i] = v;
     }
-    uint16_t* st = (uint16_t*)(out + y.btab_bytes);
+    uint16_t* st = (uint16_t*)(out + y.btab_bytes + stream_off);       // projected: one stream per object
     const int64_t n_elems = (int64_t)(y.PV * y.P1 + y.P2) * 16 * 64 * 8;
     const int per1 = 2 * y.SZ + 2 + CHUNK_STAGES, per2 = 2 + CHUNK_STAGES;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += (int64_t)gridDim.x * blockDim.x) {
@@ -290,6 +290,8 @@ struct MfmaArgs {
     int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
     int use_code_viewdirs, num_freqs;
     float freq_factor;
+    int wgs_per_obj;               // > 0: workgroups are assigned per OBJECT (projected streams of several objects: a tile never
+    int64_t obj_stream_stride;     //      mixes objects); object o streams from stream + o * obj_stream_stride
     int tiles_per_wg;              // plain launch: workgroup b owns tiles [b tiles_per_wg, (b+1) tiles_per_wg)
     RayJob job;                    // fused render launch: workgroup b owns rays [b rays_per_wg, ...) (see pnr_common.h)
 };
@@ -422,18 +424,24 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         return q != nullptr;
     };
     int64_t p_begin, p_end, ray_begin = 0;
+    // per-object assignment (several objects with projected streams): workgroup = (object, index within the object)
+    const int wg_obj = a.wgs_per_obj > 0 ? (int)blockIdx.x / a.wgs_per_obj : 0;
+    const int wg_idx = a.wgs_per_obj > 0 ? (int)blockIdx.x - wg_obj * a.wgs_per_obj : (int)blockIdx.x;
+    const char* const stream = a.stream + (size_t)wg_obj * a.obj_stream_stride;
     if (a.job.on) {
-        ray_begin = (int64_t)blockIdx.x * a.job.rays_per_wg;
-        ray_begin = ray_begin < a.job.n_rays ? ray_begin : a.job.n_rays;
+        const int64_t rays_lim = a.wgs_per_obj > 0 ? (wg_obj + 1) * (a.pts_per_obj / a.job.K) : a.job.n_rays;
+        ray_begin = (a.wgs_per_obj > 0 ? wg_obj * (a.pts_per_obj / a.job.K) : 0) + (int64_t)wg_idx * a.job.rays_per_wg;
+        ray_begin = ray_begin < rays_lim ? ray_begin : rays_lim;
         int64_t ray_end = ray_begin + a.job.rays_per_wg;
-        ray_end = ray_end < a.job.n_rays ? ray_end : a.job.n_rays;
+        ray_end = ray_end < rays_lim ? ray_end : rays_lim;
         p_begin = ray_begin * a.job.K;
         p_end = ray_end * a.job.K;
     } else {
-        p_begin = (int64_t)blockIdx.x * a.tiles_per_wg * TILE_PTS;
-        p_begin = p_begin < a.n_points ? p_begin : a.n_points;
+        const int64_t pts_lim = a.wgs_per_obj > 0 ? (wg_obj + 1) * a.pts_per_obj : a.n_points;
+        p_begin = (a.wgs_per_obj > 0 ? wg_obj * a.pts_per_obj : 0) + (int64_t)wg_idx * a.tiles_per_wg * TILE_PTS;
+        p_begin = p_begin < pts_lim ? p_begin : pts_lim;
         p_end = p_begin + (int64_t)a.tiles_per_wg * TILE_PTS;
-        p_end = p_end < a.n_points ? p_end : a.n_points;
+        p_end = p_end < pts_lim ? p_end : pts_lim;
     }
     const int n_loc = (int)(p_end - p_begin);
     const int my_tiles = (n_loc + TILE_PTS - 1) / TILE_PTS;
@@ -463,7 +471,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     if (my_tiles > 0) prefetch_points(0, 0);
     {
         const uint32_t gl_off = (uint32_t)(wv * 4096 + lane_id() * 16);
-        const char* dma_g = a.stream;                               // global base of the stage being loaded (uniform)
+        const char* dma_g = stream;                                 // global base of the stage being loaded (uniform)
         uint32_t dma_l = __builtin_amdgcn_readfirstlane(ring_lds);  // LDS base of its slot (+ this wave's quarter)
 #pragma unroll
         for (int i = 0; i < RING_SLOTS - 1; ++i) {
@@ -475,7 +483,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 ld_rep = (ld_rep + 1 == a.ldNS) ? 0 : ld_rep + 1;
                 ld_wrap = (ld_rep == a.ldNS - 1) ? a.ldP1 + a.P2 : a.ldP1;
             }
-            dma_g = a.stream + (size_t)ld_idx * STAGE_BYTES;
+            dma_g = stream + (size_t)ld_idx * STAGE_BYTES;
             dma_l = __builtin_amdgcn_readfirstlane(ring_lds + ld_slot * STAGE_BYTES);
         }
     }
@@ -515,11 +523,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         PNR_LANE_OPERANDS;
         if (DT == PNR_BF16)
             asm volatile(PNR_XSTAGES_ASM_BF16 : PNR_ASM_STATE_OPERANDS
-                         : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
+                         : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
                          : PNR_RESBLOCK_CLOBBERS);
         else
             asm volatile(PNR_XSTAGES_ASM_F16 : PNR_ASM_STATE_OPERANDS
-                         : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
+                         : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
                          : PNR_RESBLOCK_CLOBBERS);
     };
 
@@ -663,11 +671,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             PNR_LANE_OPERANDS;
             if (DT == PNR_BF16)
                 asm volatile(PNR_XSTAGES_ASM_BF16 : PNR_ASM_STATE_OPERANDS_OUT
-                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
+                             : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
                              : PNR_RESBLOCK_CLOBBERS);
             else
                 asm volatile(PNR_XSTAGES_ASM_F16 : PNR_ASM_STATE_OPERANDS_OUT
-                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
+                             : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword), "s"(cfg2)
                              : PNR_RESBLOCK_CLOBBERS);
         };
         // ---- resblock b: [last lin_z part] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62, 203-234)
@@ -679,12 +687,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             const int cfg2z = (a.proj ? p_steps : 8) | (n_pre << 16) | (n_plain << 20);   // k-steps of the prefix (last lin_z part)
             if (DT == PNR_BF16)
                 asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
-                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
+                             : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
                                "v"(zaddr), "s"(cfg2z)
                              : PNR_RESBLOCK_CLOBBERS);
             else
                 asm volatile(PNR_RESBLOCK_ASM_F16 : PNR_ASM_STATE_OPERANDS
-                             : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
+                             : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
                                "v"(zaddr), "s"(cfg2z)
                              : PNR_RESBLOCK_CLOBBERS);
         };
@@ -874,10 +882,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         PNR_LANE_OPERANDS;
         if (DT == PNR_BF16)
             asm volatile(PNR_LINOUT_ASM_BF16 : PNR_ASM_STATE_OPERANDS
-                         : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword) : PNR_RESBLOCK_CLOBBERS);
+                         : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword) : PNR_RESBLOCK_CLOBBERS);
         else
             asm volatile(PNR_LINOUT_ASM_F16 : PNR_ASM_STATE_OPERANDS
-                         : "s"(asm_cfg), "s"(a.stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword) : PNR_RESBLOCK_CLOBBERS);
+                         : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(zaddr), "v"(bias_dword) : PNR_RESBLOCK_CLOBBERS);
         {
             // the block left rows 0..3 of the output in the wave's LDS buffer: [column group][lane (g = 0: lanes 0..15)] x float4.
             // Lanes 0..31 store the wave's 32 consecutive points.
@@ -953,10 +961,14 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     const int gathered = proj ? (mlp->d_latent - vw->lat_c[last]) / 256 : 0;
     if (proj && (vw->lat_c[last] != 256 || (mlp->d_latent - 256) % 256 != 0)) return PNR_E_PACKED;
     if (!make_layout(*mlp, y, proj, vw->n_views, gathered)) return proj ? PNR_E_PACKED : PNR_E_UNSUPPORTED;
-    if (!mlp->packed || mlp->packed_dtype != prm->precision || mlp->packed_bytes < y.total_bytes) return PNR_E_PACKED;
+    // projected: one stream per object (each holds W_z . Lat of that object's views): the blob must have been packed for
+    // exactly the objects being rendered
+    const int packed_objs = mlp->packed_objs > 0 ? mlp->packed_objs : 1;
+    if (!mlp->packed || mlp->packed_dtype != prm->precision ||
+        mlp->packed_bytes < y.btab_bytes + (uint64_t)(proj ? packed_objs : 1) * y.stream_bytes) return PNR_E_PACKED;
     if (((uintptr_t)mlp->packed & 15) != 0) return PNR_E_ALIGN;
-    if (proj) {      // the stream was packed for ONE view's latent map: it must be the map being rendered
-        if (vw->n_objs != 1 || vw->lat_h[last] * vw->lat_w[last] != proj) return PNR_E_PACKED;
+    if (proj) {      // the stream was packed for these views' latent maps: they must be the maps being rendered
+        if (vw->n_objs != packed_objs || vw->lat_h[last] * vw->lat_w[last] != proj) return PNR_E_PACKED;
     }
     if (!proj || gathered > 0) {
         if (vw->packed_dtype != prm->precision) return PNR_E_PACKED;
@@ -990,7 +1002,37 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     if (grid > MAX_GRID) grid = MAX_GRID;
     a.job = RayJob{};
     a.tiles_per_wg = 0;
-    if (job && job->on) {
+    a.wgs_per_obj = 0;
+    a.obj_stream_stride = 0;
+    if (proj && vw->n_objs > 1) {
+        // several objects with projected streams: workgroups per object, so that a workgroup streams ONE object's weights
+        const int n_objs = vw->n_objs;
+        int wpo = grid / n_objs;
+        if (wpo < 1) wpo = 1;
+        if ((int64_t)wpo * n_objs > MAX_GRID) return PNR_E_UNSUPPORTED;
+        a.obj_stream_stride = (int64_t)y.stream_bytes;
+        if (job && job->on) {
+            a.job = *job;
+            if (a.job.K < 1 || a.job.n_rays * a.job.K != n_points || !a.job.rgb_out || !a.job.depth_out) return PNR_E_SHAPE;
+            if (a.job.gen_z ? !a.job.z_out : !src.z) return PNR_E_NULL;
+            if (!a.job.from_cam && !src.rays) return PNR_E_NULL;
+            const int64_t rays_per_obj = pts_per_obj / a.job.K;
+            int64_t rpw = (rays_per_obj + wpo - 1) / wpo;
+            const int64_t min_rpw = (TILE_PTS + a.job.K - 1) / a.job.K;
+            if (rpw < min_rpw) rpw = min_rpw;
+            if (rpw * a.job.K >= 0x7fffffffLL) return PNR_E_SHAPE;
+            a.job.rays_per_wg = (int)rpw;
+            wpo = (int)((rays_per_obj + rpw - 1) / rpw);
+        } else {
+            const int64_t tiles_obj = (pts_per_obj + TILE_PTS - 1) / TILE_PTS;
+            int64_t tpw = (tiles_obj + wpo - 1) / wpo;
+            if (tpw * TILE_PTS >= 0x7fffffffLL) return PNR_E_SHAPE;
+            a.tiles_per_wg = (int)tpw;
+            wpo = (int)((tiles_obj + tpw - 1) / tpw);
+        }
+        a.wgs_per_obj = wpo;
+        grid = wpo * n_objs;
+    } else if (job && job->on) {
         // whole rays per workgroup, at least about a tile's worth of points each
         a.job = *job;
         if (a.job.K < 1 || a.job.n_rays * a.job.K != n_points || !a.job.rgb_out || !a.job.depth_out) return PNR_E_SHAPE;
@@ -1045,7 +1087,8 @@ extern "C" uint64_t pnr_packed_mlp_bytes(const pnr_mlp* mlp) {
 // texel count of the last level if (mlp, views) qualifies for the projected stream, else 0; *gathered = 256-channel
 // groups of the levels before it
 static int projectable(const pnr_mlp* mlp, const pnr_views* vw, int* gathered) {
-    if (!mlp || !vw || vw->n_objs != 1 || vw->n_views < 1 || vw->n_views > 8 || vw->n_levels < 1 || vw->n_levels > PNR_MAX_LEVELS)
+    if (!mlp || !vw || vw->n_objs < 1 || vw->n_objs > 16 || vw->n_views < 1 || vw->n_views > 8 || vw->n_levels < 1 ||
+        vw->n_levels > PNR_MAX_LEVELS)
         return 0;
     const int last = vw->n_levels - 1;
     if (!vw->latent[last] || vw->lat_c[last] != 256 || mlp->combine_layer < 1) return 0;
@@ -1063,7 +1106,7 @@ extern "C" uint64_t pnr_packed_mlp_projected_bytes(const pnr_mlp* mlp, const pnr
     int gathered = 0;
     int T = projectable(mlp, views, &gathered);
     if (!T || !make_layout(*mlp, y, T, views->n_views, gathered)) return 0;
-    return y.total_bytes;
+    return y.btab_bytes + (uint64_t)views->n_objs * (y.stream_bytes + y.proj_bytes);       // one stream (+ scratch) per object
 }
 
 extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* views, int32_t dtype, void* out,
@@ -1074,21 +1117,28 @@ extern "C" int32_t pnr_pack_mlp_projected(const pnr_mlp* mlp, const pnr_views* v
     Layout y;
     if (!T || !make_layout(*mlp, y, T, views->n_views, gathered)) return PNR_E_UNSUPPORTED;
     if (dtype != PNR_BF16 && dtype != PNR_F16) return PNR_E_UNSUPPORTED;
-    if (out_bytes < y.total_bytes) return PNR_E_WORKSPACE;
+    const int n_objs = views->n_objs;
+    if (out_bytes < y.btab_bytes + (uint64_t)n_objs * (y.stream_bytes + y.proj_bytes)) return PNR_E_WORKSPACE;
     if (((uintptr_t)out & 15) != 0) return PNR_E_ALIGN;
     if (!mlp->lin_in_w || !mlp->lin_in_b || !mlp->lin_out_w || !mlp->lin_out_b) return PNR_E_NULL;
     for (int b = 0; b < mlp->n_blocks; ++b) {
         if (!mlp->fc0_w[b] || !mlp->fc0_b[b] || !mlp->fc1_w[b] || !mlp->fc1_b[b]) return PNR_E_NULL;
         if (b < y.nb1 && (!mlp->lin_z_w[b] || !mlp->lin_z_b[b])) return PNR_E_NULL;
     }
-    float* M = (float*)((char*)out + y.btab_bytes + y.stream_bytes);
+    // blob: [bias table][stream of object 0][stream of object 1]..[fp32 M scratch of object 0]..
+    const int last = views->n_levels - 1;
+    const size_t lat_obj = (size_t)views->n_views * views->lat_c[last] * T;          // floats of one object's views in the last level
     int64_t n_out = (int64_t)y.PV * y.nb1 * HID * y.ZK;
-    hipLaunchKernelGGL(k_project_latent, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *mlp, y,
-                       views->latent[views->n_levels - 1], T, M);
-    PNR_LAUNCH_CHECK();
-    if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);
-    else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M);
-    PNR_LAUNCH_CHECK();
+    for (int o = 0; o < n_objs; ++o) {
+        float* M = (float*)((char*)out + y.btab_bytes + (uint64_t)n_objs * y.stream_bytes + (uint64_t)o * y.proj_bytes);
+        hipLaunchKernelGGL(k_project_latent, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *mlp, y,
+                           views->latent[last] + (size_t)o * lat_obj, T, M);
+        PNR_LAUNCH_CHECK();
+        const uint64_t off = (uint64_t)o * y.stream_bytes;
+        if (dtype == PNR_BF16) hipLaunchKernelGGL(k_pack_mlp<PNR_BF16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M, off);
+        else hipLaunchKernelGGL(k_pack_mlp<PNR_F16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, *mlp, y, (char*)out, (const float*)M, off);
+        PNR_LAUNCH_CHECK();
+    }
     return PNR_OK;
 }
 

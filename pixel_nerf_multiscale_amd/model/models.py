@@ -217,6 +217,7 @@ class PixelNeRFNet(torch.nn.Module):
                 self._pack_cache[key] = packed
             m.packed, m.packed_bytes, m.packed_dtype = packed.data_ptr(), packed.numel(), N.PRECISIONS[precision]
             m.packed_texels = int(views.lat_h[views.n_levels - 1] * views.lat_w[views.n_levels - 1]) if proj_bytes else 0
+            m.packed_objs = int(views.n_objs) if proj_bytes else 0
             keep.append(packed)
         return m, keep
 
