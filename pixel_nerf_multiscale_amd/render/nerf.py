@@ -44,24 +44,42 @@ class _ShardedRenderWrapper(torch.nn.Module):
             (("coarse",) if simple_output else (("coarse", "fine") if renderer.using_fine else ("coarse",)))
         self._levels = lvls
 
+        self._want_weights = False
+
         def render_shard(rays, base, seed):
             renderer.ray_index_base, renderer.forced_seed = base, seed
             try:
-                out = renderer(net, rays)
+                out = renderer(net, rays, want_weights=self._want_weights)
             finally:
                 renderer.ray_index_base, renderer.forced_seed = 0, None
-            return [t for lv in lvls() for t in (out[lv].rgb, out[lv].depth)]
+            cols = []
+            for lv in lvls():
+                cols += [out[lv].rgb, out[lv].depth] + ([out[lv].weights] if self._want_weights else [])
+            return cols
         self.sharded = ShardedRenderer(render_shard, group=group)
+
+    def _sample_counts(self):
+        r = self.renderer
+        return {"coarse": int(r.n_coarse), "fine": int(r.n_coarse) + int(r.n_fine)}
 
     def forward(self, rays, want_weights=False):
         if rays.shape[0] == 0:
             return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
-        if want_weights and not self.simple_output:
-            raise NotImplementedError("per-sample weights are not gathered across ranks; render them on one rank")
-        cols = self.sharded.gather(rays, [3, 1] * len(self._levels()))
+        # per-sample weights (nested output only, nerf.py:33-41) travel in the same all_gather as rgb and depth
+        self._want_weights = bool(want_weights) and not self.simple_output
+        widths = []
+        for lv in self._levels():
+            widths += [3, 1] + ([self._sample_counts()[lv]] if self._want_weights else [])
+        cols = self.sharded.gather(rays, widths)
         if self.simple_output:
             return cols[0], cols[1]
-        return {lv: {"rgb": cols[2 * i], "depth": cols[2 * i + 1]} for i, lv in enumerate(self._levels())}
+        per = 3 if self._want_weights else 2
+        out = {}
+        for i, lv in enumerate(self._levels()):
+            out[lv] = {"rgb": cols[per * i], "depth": cols[per * i + 1]}
+            if self._want_weights:
+                out[lv]["weights"] = cols[per * i + 2]
+        return out
 
 
 class NeRFRenderer(torch.nn.Module):

@@ -141,6 +141,11 @@ def _cpu_renderer_cls():
             out = AttrDict(coarse=AttrDict(rgb=rgb * 0.5, depth=depth * 0.5))
             if self.using_fine:
                 out.fine = AttrDict(rgb=rgb, depth=depth)
+            if want_weights:          # (1, n, K) per level, a function of the global ray index like everything else
+                idx = torch.arange(self.ray_index_base, self.ray_index_base + rays.shape[1], dtype=torch.float32)
+                out.coarse.weights = (idx[None, :, None] + torch.arange(self.n_coarse)[None, None, :] * 0.25)
+                if self.using_fine:
+                    out.fine.weights = (idx[None, :, None] * 2 + torch.arange(self.n_coarse + self.n_fine)[None, None, :] * 0.5)
             return out
     return CpuRenderer
 
@@ -158,6 +163,10 @@ def _bind_worker(rank, world, port, B, q):
         rgb, depth = render_par(all_rays[None])                        # eval/eval.py:280
         full = rend.bind_parallel(None, list(range(world)), simple_output=False)
         d = full(all_rays[None])
+        dw = full(all_rays[None], want_weights=True)                   # nested output with per-sample weights (nerf.py:33-41)
+        assert set(dw["fine"]) == {"rgb", "depth", "weights"} and tuple(dw["fine"]["weights"].shape) == (1, B, 6)
+        assert torch.equal(dw["coarse"]["weights"][0, :, 0], torch.arange(B, dtype=torch.float32))
+        assert torch.equal(dw["fine"]["weights"][0, :, 5], torch.arange(B, dtype=torch.float32) * 2 + 2.5)
         q.put((rank, render_par.sharded.base_seed, rgb.numpy().copy(), depth.numpy().copy(),
                full.sharded.base_seed, {k: {kk: vv.numpy().copy() for kk, vv in v.items()} for k, v in d.items()}))
     finally:
