@@ -37,6 +37,14 @@ def _worker(rank, world, port, name, prec, q):
         ref = rend(net, rays)
         lvl = ref.fine if rend.using_fine else ref.coarse
         ok = bool(torch.equal(rgb, lvl.rgb)) and bool(torch.equal(depth, lvl.depth))
+        # nested output with per-sample weights (nerf.py:33-41): they travel in the same all_gather
+        full = rend.bind_parallel(net, [0, 1], simple_output=False).eval()
+        dw = full(rays, want_weights=True)
+        rend.forced_seed = frame_seed(full.sharded.base_seed, 0)
+        refw = rend(net, rays, want_weights=True)
+        for lv in dw:
+            for k in ("rgb", "depth", "weights"):
+                ok = ok and bool(torch.equal(dw[lv][k], refw[lv][k]))
         q.put((rank, ok, float(rgb.abs().sum())))
     finally:
         dist.destroy_process_group()
