@@ -57,7 +57,7 @@ def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
 
 def executed_ratio(spec, net):
     """Executed / algorithmic MFMA FLOPs per point of the fused kernel for this configuration (stream layout of
-    csrc/point_mfma.hip: 32-wide k-steps; lin_in padded to 64 / 96 inputs; a bias k-step per block + one before lin_out;
+    csrc/point_mfma.hip: 32-wide k-steps; lin_in padded to 64 / 96 inputs; a bias k-step per block (not in projected blocks) + one before lin_out;
     lin_out on a 16-row fragment; where the last latent level is projected, lin_z over its texels instead of its channels)."""
     NS, L = spec["NS"], sum(c for c, _, _ in spec["lat"])
     d_in = 78 if spec["use_code_viewdirs"] else 42
@@ -68,7 +68,8 @@ def executed_ratio(spec, net):
                  and T <= 256)
     Lz = (L - 256) + ((T + 31) // 32) * 32 if projected else L
     S_in = 3 if d_in == 78 else 2
-    per_view = 32 * S_in * H + cl * (Lz * H + 32 * H + 2 * H * H)
+    bias_k = 0 if projected else 32            # projected: the block's bias rides on the W_z.Lat columns (no bias k-step)
+    per_view = 32 * S_in * H + cl * (Lz * H + bias_k * H + 2 * H * H)
     per_pt = (nb - cl) * (32 * H + 2 * H * H) + 32 * H + 16 * H
     return 2 * (NS * per_view + per_pt) / alg
 

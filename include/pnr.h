@@ -144,7 +144,8 @@ int32_t pnr_pack_mlp(const pnr_mlp* mlp, int32_t dtype, void* out, uint64_t out_
  * 4 <= Hl*Wl <= 256 texels (single-scale SRN / NMR maps; the coarsest level of the multi-scale encoder — the levels
  * before it, whole 256-channel groups, are still gathered) bilinear lookup and lin_z are both linear, so
  * lin_z_b(index(uv)) = (W_z,b . Lat) . w(uv) with w the point's 4 tap weights spread over the Hl*Wl texels.  The
- * stream then carries W_z,b . Lat (512 x Hl*Wl) in place of W_z,b (512 x d_latent) and the kernel needs no latent
+ * stream then carries W_z,b . Lat (512 x Hl*Wl; the block's bias added to every column, the tap weights summing to 1) in
+ * place of W_z,b (512 x d_latent) and the kernel needs no latent
  * gather; with several views the per-view part of the stream is laid out once per view, each copy with its own
  * view's product; with several objects the blob holds one such stream per object and the kernels assign their workgroups
  * per object.  Re-pack whenever the weights OR the latent maps change; pnr_packed_mlp_projected_bytes() returns 0 when

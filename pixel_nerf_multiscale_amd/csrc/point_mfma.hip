@@ -87,6 +87,7 @@ template <> struct Num<PNR_F16> {
 // per-point latent gather disappears (the B operand is the tap-weight image).
 struct Layout {
     int d_in, D, S_in, L, SZ, n_blocks, nb1, nb2, P1, P2, btab_floats, proj_T, ZK, PV, Gg;   // PV: per-view copies of the P1 part (projected), else 1; Gg: 256-channel groups still gathered
+    int fold;      // projected: the bias of a block with lin_z rides on the columns of W_z . Lat (no bias stages in P1)
     uint64_t btab_bytes, stream_bytes, total_bytes, proj_bytes;
 };
 static constexpr int CHUNK_STAGES = 64;
@@ -118,7 +119,10 @@ __host__ __device__ inline bool make_layout(const pnr_mlp& m, Layout& y, int pro
     y.nb1 = m.combine_layer < m.n_blocks ? m.combine_layer : m.n_blocks;
     if (y.nb1 < 0) y.nb1 = 0;
     y.nb2 = m.n_blocks - y.nb1;
-    y.P1 = 2 * y.S_in + y.nb1 * (2 * y.SZ + 2 + CHUNK_STAGES);
+    // projected: the four tap weights of a point sum to 1, so lin_z.bias[b] + fc_1.bias[b-1] is added to every texel column
+    // of W_z,b . Lat and the bias k-step of the blocks with lin_z disappears (2 stages per block)
+    y.fold = proj_T > 0 ? 1 : 0;
+    y.P1 = 2 * y.S_in + y.nb1 * (2 * y.SZ + (y.fold ? 0 : 2) + CHUNK_STAGES);
     y.P2 = y.nb2 * (2 + CHUNK_STAGES) + 2 + 1;
     y.btab_floats = ((m.n_blocks * HID + 4 + 63) / 64) * 64;
     y.btab_bytes = (uint64_t)y.btab_floats * 4;
@@ -168,7 +172,8 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
     }
     uint16_t* st = (uint16_t*)(out + y.btab_bytes + stream_off);       // projected: one stream per object
     const int64_t n_elems = (int64_t)(y.PV * y.P1 + y.P2) * 16 * 64 * 8;
-    const int per1 = 2 * y.SZ + 2 + CHUNK_STAGES, per2 = 2 + CHUNK_STAGES;
+    const int nbias1 = y.fold ? 0 : 2;               // bias stages at the head of a block with lin_z
+    const int per1 = 2 * y.SZ + nbias1 + CHUNK_STAGES, per2 = 2 + CHUNK_STAGES;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), f = (int)((e >> 9) & 15);
         int stage = (int)(e >> 13);
@@ -185,8 +190,8 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
             int s = stage - 2 * y.S_in;
             b = s / per1; s %= per1;
             if (s < 2 * y.SZ) { kind = 1; xs = s; }
-            else if (s < 2 * y.SZ + 2) { kind = 2; xs = s - 2 * y.SZ; }
-            else { kind = 3; q = s - 2 * y.SZ - 2; }
+            else if (s < 2 * y.SZ + nbias1) { kind = 2; xs = s - 2 * y.SZ; }
+            else { kind = 3; q = s - 2 * y.SZ - nbias1; }
         } else {
             int s = stage - y.P1;
             if (s < y.nb2 * per2) {
@@ -215,8 +220,16 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
             }
         } else if (kind == 1) {                          // LIN_Z k-step ks: natural k
             const int k = 32 * ks + 8 * g + j;
-            val = (M && ks >= 8 * y.Gg) ? M[(((size_t)pview * y.nb1 + b) * HID + n) * y.ZK + (k - 256 * y.Gg)]
-                                        : m.lin_z_w[b][(size_t)n * y.L + k];
+            if (M && ks >= 8 * y.Gg) {
+                const int t = k - 256 * y.Gg;            // texel column of the projected level
+                val = M[(((size_t)pview * y.nb1 + b) * HID + n) * y.ZK + t];
+                if (y.fold && t < y.proj_T) {            // the block's bias on every real texel column (tap weights sum to 1)
+                    val += m.lin_z_b[b][n];
+                    if (b > 0) val += m.fc1_b[b - 1][n];
+                }
+            } else {
+                val = m.lin_z_w[b][(size_t)n * y.L + k];
+            }
         } else if (kind == 2) {                          // bias k-step: k-slot 0 = hi, 1 = lo
             if (g == 0 && j < 2) {
                 float bv = 0.f;
@@ -684,7 +697,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             if (n_pre + n_plain == 0) return;
             PNR_LANE_OPERANDS;
             const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + (ln_ >> 4) * 16;
-            const int cfg2z = (a.proj ? p_steps : 8) | (n_pre << 16) | (n_plain << 20);   // k-steps of the prefix (last lin_z part)
+            // k-steps of the prefix (the last lin_z part) that run as x-stages; with the bias folded into the projected columns
+            // the last of them takes the place of the bias k-step (bit 24)
+            const int cfg2z = (a.proj ? p_steps - 1 : 8) | (n_pre << 16) | (n_plain << 20) | (a.proj ? 1 << 24 : 0);
             if (DT == PNR_BF16)
                 asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
                              : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),

@@ -384,9 +384,10 @@ def snapshot_hooks(E, ks0):
 def gen(dt):
     """One resblock.  Inputs after the common %0-%20: %21 cfg, %22 stream (s64), %23 ring + wave*4096 (s), %24 ring +
     lane*16 (v), %25 DMA lane offset (v), %26 LDS address of fc_0.bias[block] + 16*(lane>>4) (v), %27 bias B dword 0 (v),
-    %28 lin_z B image address + lane*16 (v), %29 = lin_z k-steps of a prefixed block | number of consecutive blocks with the
-    lin_z prefix << 16 | number of blocks without it after them << 20 (%26 names the FIRST block's bias rows; the bias k-step
-    is always part of a block).
+    %28 lin_z B image address + lane*16 (v), %29 = lin_z k-steps of a prefixed block that run as x-stages | number of
+    consecutive blocks with the lin_z prefix << 16 | number of blocks without it after them << 20 | bias folded into the last
+    lin_z k-step << 24 (%26 names the FIRST block's bias rows; the two stages at the head of the fixed part are the bias k-step,
+    or with the fold the last lin_z k-step).
     Stage order (k_pack_mlp follows it): [lin_z k-steps x 2] | bias x 2 | F(0) | F(1) G(0) | ... | F(15) G(14) | G(15), with
     F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[32c..32c+31, :] . relu(x)) and G(c) = its 2 fc_1 stages
     (x += W1[:, 32c..32c+31] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
@@ -416,19 +417,28 @@ def gen(dt):
     xstages_core(E, "%28", "%29", "%24", "%23", "%25", "%27")
     E.drain()                                                # both paths reach 9: with nothing in flight
     e("s_sub_u32 s30, s30, 1")
+    # %29 bit 24 (projected streams): the block's bias is folded into the LAST lin_z k-step (its columns W_z.Lat + bias: the
+    # tap weights sum to 1), which then takes the place of the bias k-step below — the x-stages above ran one k-step fewer
+    # and left that k-step's B pair in v16-23 (their read-ahead), so the bias pattern must not overwrite it.
+    e("s_bitcmp1_b32 %29, 24")
+    e("s_cbranch_scc1 9f")
+
+    def bias_b_operand():
+        e("v_mov_b32 v16, %27")
+        for i in range(1, 8):
+            e(f"v_mov_b32 v{16 + i}, 0")
+        e("v_mov_b32 v20, v16")
+    bias_b_operand()
     e("s_branch 9f")
     e("5:")
     e("s_sub_u32 s31, s31, 1")
+    bias_b_operand()
     e("9:")
     if "drainB" in DIAG:
         e("s_waitcnt vmcnt(0)")
     fixed_bases(E, "%24", "%23")
     e("v_add_u32 v14, s33, %26")
     e("v_mov_b32 v15, %25")
-    e("v_mov_b32 v16, %27")
-    for i in range(1, 8):
-        e(f"v_mov_b32 v{16 + i}, 0")
-    e("v_mov_b32 v20, v16")
     ACC = (40, 72)
 
     def hbias(acc, tagp):
