@@ -606,7 +606,7 @@ def gen_viewreduce():
         e("s_add_u32 s24, s24, 0x1000")
         e("s_addc_u32 s25, s25, 0")
 
-    def combine_pass(op):
+    def combine_pass(op, scale=False):
         NB, D = 10, 9
         buf = lambda t: 96 + 16 * (t % NB)
         for t in range(D):
@@ -620,6 +620,8 @@ def gen_viewreduce():
                 tmp = 68 + (i & 3)
                 e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
                 e(f"{op} v{tmp}, v{tmp}, v{b + i}")
+                if scale:
+                    e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
                 e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
 
     e("s_nop 15")
@@ -628,20 +630,19 @@ def gen_viewreduce():
     e("s_mov_b32 s34, %17")
     e("s_cmp_lg_u32 %18, 0")
     e("s_cbranch_scc1 5f")
-    e("1:")                                                   # ---- sum over parked views, then scale
+    e("s_cmp_eq_u32 s34, 1")                                 # ---- sum over parked views; the last pass also scales by 1/NS
+    e("s_cbranch_scc1 2f")                                   #      (same order of operations as sum-then-scale: identical bits)
+    e("1:")
     e("s_mov_b64 s[24:25], s[26:27]")
     combine_pass("v_add_f32")
     e("s_add_u32 s26, s26, 0x10000")
     e("s_addc_u32 s27, s27, 0")
     e("s_sub_u32 s34, s34, 1")
-    e("s_cmp_lg_u32 s34, 0")
+    e("s_cmp_lg_u32 s34, 1")
     e("s_cbranch_scc1 1b")
-    for t in range(16):
-        for i in range(16):
-            tmp = 68 + (i & 3)
-            e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
-            e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
-            e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
+    e("2:")
+    e("s_mov_b64 s[24:25], s[26:27]")
+    combine_pass("v_add_f32", scale=True)
     e("s_branch 6f")
     e("5:")                                                   # ---- max over parked views
     e("s_mov_b64 s[24:25], s[26:27]")
