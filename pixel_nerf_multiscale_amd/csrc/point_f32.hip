@@ -6,19 +6,20 @@
 
 namespace pnr {
 
+// train_f32.hip: y (+)= act(x) W^T + b on the fp32 MFMA tile kernel (v_mfma_f32_32x32x2_f32, 128 x 128 tiles)
+int32_t linear_f32_mfma(const float* X, int ldx, const float* W, int ldw, const float* b, bool relu_in, bool accum, float* Y,
+                        int ldy, int64_t M, int N, int K, hipStream_t s);
+
 template <bool RELU_IN, bool ACCUM>
 static int32_t linear(const float* X, int ldx, const float* W, const float* b, float* Y, int ldy, int M, int N, int K,
                       hipStream_t s) {
-    dim3 grid((M + 63) / 64, (N + 63) / 64);
-    hipLaunchKernelGGL((k_linear_f32<RELU_IN, ACCUM>), grid, dim3(256), 0, s, X, ldx, W, b, Y, ldy, M, N, K);
-    PNR_LAUNCH_CHECK();
-    return PNR_OK;
+    return linear_f32_mfma(X, ldx, W, K, b, RELU_IN, ACCUM, Y, ldy, M, N, K, s);
 }
 
 static const int F32_CHUNK = 16384;   // points per chunk
 
 uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
-    uint64_t per_pt = (uint64_t)vw->n_views * (mlp->d_latent + mlp->d_in + 2ull * mlp->d_hidden) + 4;
+    uint64_t per_pt = (uint64_t)vw->n_views * (((mlp->d_latent + mlp->d_in + 3) & ~3) + 2ull * mlp->d_hidden) + 4;
     return per_pt * F32_CHUNK * sizeof(float) + 256;
 }
 
@@ -51,7 +52,8 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                   int64_t pts_per_obj, float* out, void* workspace, uint64_t ws_bytes, hipStream_t s) {
     if (ws_bytes < point_f32_workspace_bytes(mlp, vw)) return PNR_E_WORKSPACE;
     if (mlp->d_out != 4) return PNR_E_SHAPE;
-    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden, E = L + Din;
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
+    const int E = (L + Din + 3) & ~3;              // row stride of zx: 16-byte rows for the GEMM's vector loads
     float* zx = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     float* x = zx + (size_t)F32_CHUNK * NS * E;
     float* h = x + (size_t)F32_CHUNK * NS * H;

@@ -993,6 +993,15 @@ __global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restr
     db[n] = acc;
 }
 
+// y (+)= act(x) W^T + b on the fp32 MFMA tile kernel, for the fp32 inference path (point_f32.hip): the same GEMM the taped
+// training forward uses.  W (N, K) row-major as nn.Linear stores it; accum adds to what Y holds.
+int32_t linear_f32_mfma(const float* X, int ldx, const float* W, int ldw, const float* b, bool relu_in, bool accum, float* Y,
+                        int ldy, int64_t M, int N, int K, hipStream_t s) {
+    const float* R = accum ? Y : nullptr;
+    if (relu_in) return gemm<true, false>(X, ldx, W, ldw, b, R, ldy, nullptr, 0, Y, ldy, M, N, K, s, 0);
+    return gemm<false, false>(X, ldx, W, ldw, b, R, ldy, nullptr, 0, Y, ldy, M, N, K, s, 0);
+}
+
 // Ordered sum of the per-split partials: out[i] += part[0][i] + part[1][i] + ... (fixed order -> run-to-run identical bits)
 __global__ void k_reduce_parts(const float* __restrict__ part, int nz, size_t zs, float* __restrict__ out, int ld, int rows, int cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
