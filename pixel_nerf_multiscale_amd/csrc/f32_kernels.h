@@ -52,59 +52,6 @@ static __global__ void k_features_f32(pnr_views vw, PointSrc src, int64_t g0, in
     zx[(size_t)col * ldz + e] = val;
 }
 
-// Y[M,N] (+)= act(X[M,K]) W[N,K]^T + b ;  64x64 tile, K-step 16, 4x4 per thread, k-ordered fmaf chain.
-template <bool RELU_IN, bool ACCUM>
-static __global__ void __launch_bounds__(256) k_linear_f32(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
-                                                    const float* __restrict__ b, float* __restrict__ Y, int ldy,
-                                                    int M, int N, int K) {
-    __shared__ float Xs[16][64 + 4];
-    __shared__ float Ws[16][64 + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int li = tid + i * 256;          // 0..1023
-            int r = li >> 4, kk = li & 15;   // row in tile, k in tile
-            int m = m0 + r, n = n0 + r, k = k0 + kk;
-            float xv = (m < M && k < K) ? X[(size_t)m * ldx + k] : 0.f;
-            if (RELU_IN) xv = fmaxf(xv, 0.f);
-            Xs[kk][r] = xv;
-            Ws[kk][r] = (n < N && k < K) ? Wt[(size_t)n * K + k] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float xa[4], wb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; wb[i] = Ws[kk][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xa[i], wb[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + ty * 4 + i;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int n = n0 + tx * 4 + j;
-            if (n >= N) continue;
-            float v = acc[i][j] + b[n];
-            if (ACCUM) v += Y[(size_t)m * ldy + n];
-            Y[(size_t)m * ldy + n] = v;
-        }
-    }
-}
-
 // x (NS, CH, H) -> (CH, H): mean or max over the view axis (util.combine_interleaved, util.py:466-476)
 static __global__ void k_combine_f32(const float* __restrict__ x, int NS, int64_t per_view, int combine_type,
                               float* __restrict__ y) {
