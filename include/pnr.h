@@ -193,8 +193,9 @@ int32_t pnr_point_mlp(const pnr_params* params, const pnr_mlp* mlp, const pnr_vi
 /* ---- the whole path: NeRFRenderer.forward with a PixelNeRFNet model (render/nerf.py:251-303) --- */
 /* rays (N,8), N = SB*B, rays_per_obj = B.  fine may be NULL (mlp_fine=None -> coarse MLP, backup2:258).
  * PNR_BF16 / PNR_F16: each pass is ONE kernel launch — coarse positions (sample_coarse) are generated in the kernel, every
- * workgroup composites the rays it evaluated — plus one resampling launch (sample_fine .. sort) between the passes; the
- * results are bit-identical to calling the stage entry points above in sequence.  PNR_F32: the stages in sequence. */
+ * workgroup composites the rays it evaluated; the resampling (sample_fine .. sort) runs at the head of the fine launch for
+ * batches of up to 2048 rays and as one launch between the passes above that; the results are bit-identical to calling the
+ * stage entry points above in sequence.  PNR_F32: the stages in sequence. */
 uint64_t pnr_workspace_bytes(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
                              int64_t n_rays);
 int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,

@@ -292,9 +292,20 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         if ((rc = point_mfma(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s, &job))) return rc;
         if (outputs->ev_point_end) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_end, s));
         if (Kf == 0) return PNR_OK;
-        if ((rc = sample_fine_launch(rays, cam ? cam->zn : 0.f, cam ? cam->zf : 0.f, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd,
-                                     params->depth_std, params->lindisp, nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream)))
-            return rc;
+        // Small batches: the fine launch resamples its own rays first (sample_fine .. sort, one wave per ray in the wave's LDS
+        // buffer) — no third launch.  Whole frames: a workgroup owns ~64 rays and would sort them 4 at a time in front of its
+        // first tile (measured +1.3 % frame time at 16384 rays x 64+32), against 0.5 % for one chip-wide resampling launch.
+        int P2 = 1;
+        while (P2 < Kt) P2 <<= 1;
+        const bool in_kernel = (uint64_t)(P2 + Kc + 2) * 4 <= 16384 && n_rays <= 2048;
+        if (!in_kernel) {
+            if ((rc = sample_fine_launch(rays, cam ? cam->zn : 0.f, cam ? cam->zf : 0.f, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd,
+                                         params->depth_std, params->lindisp, nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream)))
+                return rc;
+        }
+        job.resample = in_kernel ? 1 : 0;
+        job.fine = FineArgs{Kc, Kf - Kfd, Kfd, P2, params->lindisp, params->depth_std, nz.u, nz.r, nz.g, seed};
+        job.zc = zc; job.wc = w_c; job.depth_c = dep_c; job.z_fine = zf;
         job.K = Kt; job.gen_z = 0; job.noise_c = nullptr; job.z_out = nullptr;
         job.w_out = outputs->fine_weights; job.rgb_out = outputs->fine_rgb; job.depth_out = outputs->fine_depth;
         PointSrc srcf{rays, zf, Kt, nullptr, nullptr};

@@ -357,6 +357,12 @@ struct RayJob {
     const float* noise_c; uint64_t seed; int64_t ray_base;
     float* z_out; float* w_out; float* rgb_out; float* depth_out;      // w_out may be NULL
     RayCam cam; int pix0;
+    // fine pass: the launch first resamples its own rays (sample_fine .. sort, nerf.py:120-161,285-295) from the coarse pass's
+    // outputs into z_fine (= PointSrc.z of this launch), every workgroup for the rays it owns
+    int resample;
+    FineArgs fine;
+    const float* zc; const float* wc; const float* depth_c;
+    float* z_fine;
 };
 
 // Where a point comes from (see pnr_point_mlp in pnr.h).

@@ -481,6 +481,31 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             glds_gather_xyz((const char*)((lane < 32 ? a.src.xyz : a.src.dirs) + gp * 3), dst);     // 12-byte records
         }
     };
+    if (flag(a.job.resample)) {
+        // ---------------- fine pass: resample this workgroup's rays first (one wave per ray, the wave's 16-KiB B-image buffer as
+        // scratch), the function k_sample_fine runs.  The positions go to z_fine, which the tile prefetch then gathers from:
+        // the stores are drained and the workgroup synchronised before the first gather (nothing of z_fine is in this CU's L1).
+        const FineArgs f = a.job.fine;
+        const int Kt = f.Kc + f.n_imp + f.n_dep;
+        float* cdf = (float*)(smem + LDS_Z + wv * ZBUF_BYTES);
+        float* buf = cdf + f.Kc + 2;
+        const int lane = lane_id();
+        const int n_rays_loc = n_loc / Kt;
+        auto wave_sync = []() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's LDS accesses are ordered; this orders the compiler
+        };
+        for (int lr = wv; lr < n_rays_loc; lr += 4) {
+            const int64_t ray = ray_begin + lr;
+            const float near = flag(a.job.from_cam) ? a.job.cam.zn : a.src.rays[ray * 8 + 6];
+            const float far = flag(a.job.from_cam) ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
+            const float depth = f.n_dep > 0 ? a.job.depth_c[ray] : 0.f;
+            sample_fine_ray<false>(f, a.job.zc + ray * f.Kc, a.job.wc ? a.job.wc + ray * f.Kc : nullptr, depth, near, far, ray,
+                                   a.job.ray_base + ray, true, cdf, buf, a.job.z_fine + ray * Kt, lane, wave_sync);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     if (my_tiles > 0) prefetch_points(0, 0);
     {
         const uint32_t gl_off = (uint32_t)(wv * 4096 + lane_id() * 16);
@@ -821,7 +846,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     // the rays the previous tile finished: every wave has been through the vmcnt(0) and the barriers of the
                     // LIN_IN statement since it stored that tile's outputs, so they are in the L2 for any wave to read
                     int upto = tile * TILE_PTS;
-                    upto = __builtin_amdgcn_readfirstlane((int)((uint32_t)(upto < n_loc ? upto : n_loc) / (uint32_t)a.job.K));
+                    int Kc_q = a.job.K;
+                    asm volatile("" : "+s"(Kc_q));             // divisor formed here (see lane_id)
+                    upto = __builtin_amdgcn_readfirstlane((int)((uint32_t)(upto < n_loc ? upto : n_loc) / (uint32_t)Kc_q));
                     composite_rays(rays_done, upto);
                     rays_done = upto;
                 }

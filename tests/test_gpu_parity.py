@@ -722,12 +722,14 @@ def test_resnetfc_forward_and_encoder_index_are_native_stage_calls(name):
         assert maxdiff(out.cpu(), ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("Kc,Kf,Kfd,n_rays", [(150, 100, 30, 5), (1, 0, 0, 131), (37, 11, 11, 131), (128, 64, 0, 3), (300, 212, 100, 2)])
+@pytest.mark.parametrize("Kc,Kf,Kfd,n_rays", [(150, 100, 30, 5), (1, 0, 0, 131), (37, 11, 11, 131), (128, 64, 0, 3), (300, 212, 100, 2),
+                                               (24, 16, 8, 2300)])       # > 2048 rays: the resampling is its own launch
 @pytest.mark.parametrize("name,prec", [("full_ns1", "bf16"), ("full_ns3", "fp16")])
 def test_fused_render_launch_ragged_sample_counts(name, prec, Kc, Kf, Kfd, n_rays):
     """The fused launch against the staged launches where rays do not line up with the 128-point tiles: rays longer than a
     tile (a ray is finished — and composited — several tiles after it started), one sample per ray, sample counts that are
-    not multiples of anything, fewer rays than workgroups; in-kernel noise.  Bit-identical pixels, depths, weights, positions."""
+    not multiples of anything, fewer rays than workgroups, and both resampling routes (inside the fine launch up to 2048
+    rays, a separate launch above); in-kernel noise.  Bit-identical pixels, depths, weights, positions."""
     from hip_util import setup
     fx, spec, net, rend = setup(name, precision=prec)
     rend.fixed_noise = None
