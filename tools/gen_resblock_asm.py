@@ -363,22 +363,28 @@ def gen_xstages(dt):
     return E.L
 
 
-def bias_kstep_with_snapshot(E, i0, first_hooks=None):
-    """The block's bias k-step as stages i0, i0+1 of the fixed part (B = v16-23 = bias pair): the second stage carries the
-    snapshot relu(x) -> XB of row groups 0-15 (k-steps 0-7), whose bias MFMAs ran a stage earlier.  Row groups 16-31 are
-    converted by the caller inside the next stage (snapshot_hooks(8))."""
+def bias_kstep_with_snapshot(E, i0):
+    """The block's head k-step (the bias k-step, or with the fold the last lin_z k-step) as stages i0, i0+1 of the fixed part
+    (B = v16-23), carrying the snapshot relu(x) -> XB just in time: a row group is final once ITS fragment of this k-step has
+    run (fragment f of the first stage = row group f, of the second = row group 16 + f), so k-step ks of the snapshot (row
+    groups 2 ks, 2 ks + 1) is converted two fragments later — k-steps 0-4 inside the first stage, 5-10 inside the second,
+    11-15 by the caller in the first fragments of the next stage (tail_snapshot_hooks), none of which reads XB before
+    fragment 11.  256 conversions in ONE stage made that stage VALU-bound (1024 issue cycles against 512 of MFMA); spread
+    like this no stage carries more than 192."""
     def mm_half(half):
         def mm(f):
             rg = 16 * half + f
             return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {BX(cg)}, {X(rg, cg)}" for cg in range(2)]
         return mm
-    fixed_stage(E, i0, mm_half(0), first_hooks)
-    fixed_stage(E, i0 + 1, mm_half(1), snapshot_hooks(E, 0))
+    snap = lambda ks: (lambda: E.snapshot_ks(ks))
+    fixed_stage(E, i0, mm_half(0), {3: snap(0), 5: snap(1), 7: snap(2), 9: snap(3), 11: snap(4)})
+    fixed_stage(E, i0 + 1, mm_half(1), {0: snap(5), 1: snap(6), 2: snap(7), 4: snap(8), 6: snap(9), 8: snap(10)})
 
 
-def snapshot_hooks(E, ks0):
-    """k-steps ks0 .. ks0+7, one per two fragments (fragments 0, 2, .., 14)."""
-    return {2 * i: (lambda ks=ks0 + i: E.snapshot_ks(ks)) for i in range(8)}
+def tail_snapshot_hooks(E):
+    """k-steps 11-15 of the snapshot (row groups 22-31, final at the end of the head k-step) in fragments 0, 2, .., 8 of the
+    stage that follows it."""
+    return {2 * i: (lambda ks=11 + i: E.snapshot_ks(ks)) for i in range(5)}
 
 
 def gen(dt):
@@ -489,10 +495,10 @@ def gen(dt):
         fixed_stage(E, i, mm_fc1(0))
         fixed_stage(E, i + 1, mm_fc1(1))
 
-    # chunk 1's fc_0.bias rows into the second accumulator, then F(0) with the snapshot of k-steps 8-15 in its first stage
+    # chunk 1's fc_0.bias rows into the second accumulator, then F(0) with the last five k-steps of the snapshot in its first stage
     hbias(ACC[1], "g")
     E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
-    F(ACC[0], 2, snapshot_hooks(E, 8), need_bias=False)
+    F(ACC[0], 2, tail_snapshot_hooks(E), need_bias=False)
     # the loop head: outstanding = [g-bias reads?]  make the state explicit: the g reads are waited for here
     E.need([f"g{rgl}{cg}" for rgl in range(2) for cg in range(2)])
     if "drainC" in DIAG:
@@ -560,9 +566,8 @@ def gen_linout(dt):
 
     def mm(f):
         return [f"{E.mfma} v[{40 + 4 * cg}:{43 + 4 * cg}], {A(f & 7)}, {XB(f, cg)}, v[{40 + 4 * cg}:{43 + 4 * cg}]" for cg in range(2)]
-    # k-steps 8-15 are converted while k-steps 0-7 are multiplied: k-step 8+i is complete after fragment i, used at fragment 8+i
-    hooks = {i: (lambda ks=8 + i: E.snapshot_ks(ks)) for i in range(8)}
-    fixed_stage(E, 2, mm, hooks)
+    # fragment f multiplies k-step f: k-steps 0-10 are converted by the head k-step above, 11-15 in fragments 0-8 here
+    fixed_stage(E, 2, mm, tail_snapshot_hooks(E))
     E.drain()
     e("s_nop 15")
     e("s_nop 15")
