@@ -808,3 +808,36 @@ def test_projected_stream_several_objects(prec, floor, NS, SB, N, lat):
     assert _psnr(outs["proj"], outs["gen"]) >= floor
     assert _psnr(pts["proj"][..., :3], pts["fp32"][..., :3]) >= floor
     assert _psnr(pts["proj"][..., :3], pts["gen"][..., :3]) >= floor
+
+
+def test_full_dtu_frame_at_baseline_size():
+    """BASELINE cfg 4 at its full size — one 400 x 300 frame, 3 source views, 128 samples per ray, disparity sampling, black
+    background (120 000 rays, 15.4 M points in one launch) — through the size-independent properties the domain offers, plus
+    the identity of the two ray sources at that size: rays from the tensor vs rays formed in the kernel from the camera, and
+    the first / second half of the frame rendered as separate calls with ray_index_base (the sharding identity)."""
+    from hip_util import build_net, build_renderer
+    from pixel_nerf_multiscale_amd import util
+    spec = dict(gu.CASES["full_dtu_ns3"])
+    poses = np.stack([gu.pose_spherical(30.0 * v, -20.0, spec["radius"]) for v in range(spec["NS"])])[None]
+    net = build_net(spec, poses, "cuda", "bf16")
+    rend = build_renderer(spec)
+    rend.forced_seed = 123
+    W, H = spec["image"]
+    assert (W, H, spec["Kc"], spec["NS"]) == (400, 300, 128, 3)
+    pose = util.pose_spherical(75.0, -25.0, spec["radius"])
+    rgb, depth = rend.render_image(net, pose, W, H, spec["focal"], spec["z_near"], spec["z_far"])
+    assert rgb.shape == (H, W, 3) and bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5            # sum w c, c in [0,1], sum w <= 1, black background
+    assert float(depth.min()) >= 0.0 and float(depth.max()) <= spec["z_far"] + 1e-3
+    rays = util.gen_rays_device(pose, W, H, spec["focal"], spec["z_near"], spec["z_far"], device="cuda")
+    ref = rend(net, rays[None], want_weights=True)
+    assert torch.equal(rgb.reshape(-1, 3), ref.coarse.rgb[0]) and torch.equal(depth.reshape(-1), ref.coarse.depth[0])
+    w = ref.coarse.weights[0]
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+    half = rays.shape[0] // 2
+    parts = []
+    for lo, hi in ((0, half), (half, rays.shape[0])):
+        rend.ray_index_base = lo
+        parts.append(rend(net, rays[None, lo:hi]).coarse.rgb[0])
+    rend.ray_index_base = 0
+    assert torch.equal(torch.cat(parts), ref.coarse.rgb[0])
