@@ -915,7 +915,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #undef PNR_X_TILES
 #undef PNR_X_TILES_IN
         // ---- the blocks after the view reduction
-        for (int i = (MULTIVIEW || !one_part) ? 0 : 1; i < 1; ++i) {       // a loop, not an `if`: see view_pass
+        // (a loop, not an `if`: see view_pass; with no lin_z block at all the view pass has run none of them)
+        for (int i = (MULTIVIEW || !one_part || a.nb1 == 0) ? 0 : 1; i < 1; ++i) {
             resblocks(a.nb1, 0, a.n_blocks - a.nb1);
             STAMP_ACC(6, st_t);
         }
