@@ -43,6 +43,11 @@ WORKLOADS = {
                                                  lat=[(64, 64, 64), (64, 64, 64), (128, 32, 32), (256, 16, 16)],
                                                  focal=131.25, radius=1.3, z=(0.8, 1.8), white=True, lindisp=False, cv=True),
 }
+# BASELINE cfg 5 "hierarchical 32/64/128": the three points of the sample schedule, (Kc, Kf, Kfd) in conf/default.conf's 4:2:1
+# ratio (reference render/nerf.py:318-338 sched_step switches between such points)
+for _kc in (32, 128):
+    WORKLOADS[f"multiscale_cars_2view_128x128_k{_kc}+{_kc // 2}"] = dict(
+        WORKLOADS["multiscale_cars_2view_128x128_k64+32"], Kc=_kc, Kf=_kc // 2, Kfd=_kc // 4)
 DEFAULT = "srn_chairs_1view_128x128_k128"
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 
@@ -55,17 +60,20 @@ def flops_per_point(NS, L, d_in, d_hidden=512, n_blocks=5, combine_layer=3):
     return 2 * (NS * per_view + per_pt)
 
 
-def executed_ratio(spec, net):
+def executed_ratio(spec, net, precision):
     """Executed / algorithmic MFMA FLOPs per point of the fused kernel for this configuration (stream layout of
     csrc/point_mfma.hip: 32-wide k-steps; lin_in padded to 64 / 96 inputs; a bias k-step per block (not in projected blocks) + one before lin_out;
-    lin_out on a 16-row fragment; where the last latent level is projected, lin_z over its texels instead of its channels)."""
+    lin_out on a 16-row fragment; where the last latent level is projected, lin_z over its texels instead of its channels).
+    Whether the stream is the projected one is read from the packed struct the kernel is handed, not re-derived."""
+    if precision == "fp32":
+        return 1.0
     NS, L = spec["NS"], sum(c for c, _, _ in spec["lat"])
     d_in = 78 if spec["use_code_viewdirs"] else 42
     H, nb, cl = 512, 5, 3
     alg = flops_per_point(NS, L, d_in)
-    T = spec["lat"][-1][1] * spec["lat"][-1][2]                # the projected (last) level
-    projected = (net.project_latent and spec["SB"] == 1 and NS <= 8 and spec["lat"][-1][0] == 256 and (L - 256) % 256 == 0
-                 and T <= 256)
+    v, _ = net.views_struct(precision)
+    T = int(net.mlp_struct(net.mlp_coarse, precision, v)[0].packed_texels)      # texels of the projected (last) level, 0 = general stream
+    projected = T > 0
     Lz = (L - 256) + ((T + 31) // 32) * 32 if projected else L
     S_in = 3 if d_in == 78 else 2
     bias_k = 0 if projected else 32            # projected: the block's bias rides on the W_z.Lat columns (no bias k-step)
@@ -74,24 +82,41 @@ def executed_ratio(spec, net):
     return 2 * (NS * per_view + per_pt) / alg
 
 
+def source_hash():
+    """Identity of the kernel sources this library was built from (csrc/ + include/): a PMC summary names the hash it was
+    collected on, and its traffic figure is only quoted for the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "pixel_nerf_multiscale_amd", "csrc")
+    for f in sorted(os.listdir(base)) + ["../../include/pnr.h"]:
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(base, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, precision):
     """(bytes, source) — HBM-side bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need
-    separate rocprofv3 --pmc passes, so the figure is read from the committed summary of THIS command on the build the
-    summary names (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh):
+    separate rocprofv3 --pmc passes, so the figure is read from the committed summary of THIS command
+    (profiles/latest_pmc_bench_default.txt, written by tools/pmc_passes.sh) — and only when that summary was collected on
+    the kernel sources this library was built from (its `# sources:` line = source_hash()); otherwise (None, reason).
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 tallies the
-    128-B requests of wide coalesced reads at 64 B).  (None, None) when no summary matches."""
+    128-B requests of wide coalesced reads at 64 B)."""
     if workload != DEFAULT or precision != "bf16":
         return None, None
     rel = os.path.join("profiles", "latest_pmc_bench_default.txt")
     try:
-        vals, build_id = {}, "unknown build"
+        vals, build_id, src = {}, "unknown build", None
         for line in open(os.path.join(ROOT, rel)):
             parts = line.split()
             if line.startswith("# build:"):
                 build_id = line.split(":", 1)[1].strip()
+            if line.startswith("# sources:"):
+                src = line.split(":", 1)[1].strip()
             if len(parts) >= 4 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[parts[1]] = float(parts[3].split("=")[1])
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"{rel} (committed rocprofv3 --pmc passes of this command, {build_id}); not measured in this run"
+        if src != source_hash():
+            return None, f"{rel} was collected on other kernel sources ({src} vs {source_hash()}): no traffic figure for this build"
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"{rel} (committed rocprofv3 --pmc passes of this command, {build_id}, sources {src}); not measured in this run"
     except Exception:
         return None, None
 
@@ -201,13 +226,13 @@ def time_workload(workload, precision, device, steps, warmup, world=1, scaling="
         "config": {"workload": workload, "rays_per_step": R_total, "rays_per_gpu": rays_rank0,
                    "samples_per_ray": spec["Kc"] + spec["Kf"], "n_coarse": spec["Kc"], "n_fine": spec["Kf"],
                    "source_views": spec["NS"], "latent": spec["lat"], "parallelism": f"ray-shard x{world} + all_gather"},
-        "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)", "achieved": achieved, "peak": peak,
+        "roofline": {"bound": "mfma", "kernel": "k_point_mfma (coarse pass)" if precision != "fp32" else "fp32 point network of the coarse pass (k_mgemm_f32 chain)", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "kernel_ms": k_ms, "flops_per_launch": flops_launch,
                      # transparency: where the kernel evaluates lin_z as (W_z . Lat) . w over the Hl*Wl texels
                      # (pnr_pack_mlp_projected) it executes fewer MFMA FLOPs than the reference algorithm's count, which
                      # is what `achieved` is priced on; frac_executed prices the executed ones
-                     "executed_flops_per_launch": flops_launch * executed_ratio(spec, net),
-                     "frac_executed": achieved / peak * executed_ratio(spec, net)},
+                     "executed_flops_per_launch": flops_launch * executed_ratio(spec, net, precision),
+                     "frac_executed": achieved / peak * executed_ratio(spec, net, precision)},
         # SURVEY §8d asks for the HBM figure alongside: algorithmic bytes of the fused launch are 48 B/ray (ray in, pixel out)
         # plus the frame constants; by design the launch also writes and re-reads rgb-sigma and z once (16 + 4 B per point,
         # L2-resident).  Against 8 TB/s this is ~0: the launch is judged on the MFMA fraction.
@@ -233,9 +258,63 @@ def psnr_vs_fp32_path(workload, precision, device, rend, net, rays, n_sample=204
     return psnr(a[lvl].rgb.cpu(), b[lvl].rgb.cpu()), psnr(a.coarse.rgb.cpu(), b.coarse.rgb.cpu())
 
 
-# dtype BASELINE.json names per config (cfg5 "fp16 MFMA fc"; bf16 elsewhere)
-SECONDARY = [("srn_chairs_1view_128x128_k64+32", "bf16"), ("nmr_3view_64x64_k64+32", "bf16"),
-             ("dtu_3view_400x300_k128", "bf16"), ("multiscale_cars_2view_128x128_k64+32", "fp16")]
+# The other BASELINE.json shapes, timed in the same run.  dtype: what BASELINE.json names for the config where it names one
+# (cfg 2 bf16, cfg 5 "fp16 MFMA fc"); fp16 — what precision="auto" selects, the only 16-bit format that meets SURVEY §8(c)'s
+# 50 dB on every shape — where it names none (cfg 3, cfg 4), with the other 16-bit format beside it for cfg 2 and cfg 4.
+# The headline frame again in fp16 (same kernel, same speed, ~18 dB closer) and on the fp32 path (the reference's own
+# arithmetic: k_mgemm_f32 chain, priced against the 157.3 TFLOP/s fp32 matrix peak).
+SECONDARY = [(DEFAULT, "fp16"), (DEFAULT, "fp32"),
+             ("srn_chairs_1view_128x128_k64+32", "bf16"), ("srn_chairs_1view_128x128_k64+32", "fp16"),
+             ("nmr_3view_64x64_k64+32", "fp16"),
+             ("dtu_3view_400x300_k128", "fp16"), ("dtu_3view_400x300_k128", "bf16"),
+             ("multiscale_cars_2view_128x128_k32+16", "fp16"), ("multiscale_cars_2view_128x128_k64+32", "fp16"),
+             ("multiscale_cars_2view_128x128_k128+64", "fp16")]
+
+
+def stage_kernels_hbm(device, n_launch=5):
+    """SURVEY §8(d)'s HBM figure for the memory-bound stand-alone stages, measured: k_sample_coarse and k_composite
+    (csrc/stage_kernels.hip; reference render/nerf.py:98-118,223-249) on the 120 000-ray DTU frame at K = 128, hipEvents on
+    the stream they run on.  Algorithmic bytes per ray (DESIGN.md 4.3): sample_coarse reads near/far (8 B) and writes 4K;
+    composite reads the ray (32 B), z (4K) and rgb-sigma (16K) and writes the pixel (16 B) and the weights (4K)."""
+    import ctypes as C
+    from pixel_nerf_multiscale_amd import _native as N
+    spec, net, rend, rays = build("dtu_3view_400x300_k128", "fp32", device)
+    del net
+    r = rays.reshape(-1, 8).contiguous()
+    n, K = r.shape[0], spec["Kc"]
+    rgbs = torch.rand(n, K, 4, device=device)
+    ev = [C.c_void_p() for _ in range(2)]
+    for h in ev:
+        N.check(N.lib.pnr_event_create(C.byref(h)), "pnr_event_create")
+    stream = N.current_stream(device)
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize()
+        N.check(N.lib.pnr_event_record(ev[0], stream), "pnr_event_record")
+        for _ in range(n_launch):
+            fn()
+        N.check(N.lib.pnr_event_record(ev[1], stream), "pnr_event_record")
+        ms = C.c_float()
+        N.check(N.lib.pnr_event_elapsed_ms(ev[0], ev[1], C.byref(ms)), "pnr_event_elapsed_ms")
+        return ms.value / n_launch
+
+    # output buffers allocated once: the timed region holds launches only
+    z = torch.empty(n, K, device=device)
+    w, rgb, depth = torch.empty(n, K, device=device), torch.empty(n, 3, device=device), torch.empty(n, device=device)
+    null = N.pnr_noise()
+    ms_s = timed(lambda: N.check(N.lib.pnr_sample_coarse(N.ptr(r), n, K, int(spec["lindisp"]), null.noise_c, 1234, 0, N.ptr(z),
+                                                         stream), "pnr_sample_coarse"))
+    ms_c = timed(lambda: N.check(N.lib.pnr_composite(N.ptr(r), N.ptr(z), N.ptr(rgbs), n, K, int(spec["white_bkgd"]), N.ptr(w),
+                                                     N.ptr(rgb), N.ptr(depth), stream), "pnr_composite"))
+    for h in ev:
+        N.lib.pnr_event_destroy(h)
+    out = []
+    for name, ms, bpr in (("k_sample_coarse", ms_s, 8 + 4 * K), ("k_composite", ms_c, 32 + 4 * K + 16 * K + 16 + 4 * K)):
+        gbps = n * bpr / (ms * 1e-3) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "rays": n, "samples_per_ray": K, "algorithmic_bytes_per_ray": bpr,
+                    "us_per_launch": ms * 1e3, "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0})
+    return out
 
 
 def self_launch(args):
@@ -322,14 +401,17 @@ def main():
         # the other BASELINE.json shapes, driver-timed in the same run: rays/s, dominant-kernel fraction, PSNR of the
         # low-precision kernel vs the fp32 HIP path on a 2048-ray sample of the frame
         del net, rend, rays
+        out["roofline"]["stage_kernels_hbm"] = stage_kernels_hbm(device)
         sec = []
         for wl, prec in SECONDARY:
             r2, (spec2, net2, rend2, rays2) = time_workload(wl, prec, device, args.secondary_steps, 1)
-            p_final, p_coarse = psnr_vs_fp32_path(wl, prec, device, rend2, net2, rays2)
-            sec.append({"workload": wl, "dtype": prec, "value": r2["value"], "unit": "rays/s", "steps": args.secondary_steps,
-                        "ms_per_step": r2["ms_per_step"], "kernel_ms": r2["roofline"]["kernel_ms"],
-                        "roofline_frac": r2["roofline"]["frac"], "roofline_frac_executed": r2["roofline"]["frac_executed"],
-                        "psnr_vs_fp32_path_db": p_final, "psnr_coarse_vs_fp32_path_db": p_coarse})
+            e = {"workload": wl, "dtype": prec, "value": r2["value"], "unit": "rays/s", "steps": args.secondary_steps,
+                 "ms_per_step": r2["ms_per_step"], "kernel": r2["roofline"]["kernel"], "kernel_ms": r2["roofline"]["kernel_ms"],
+                 "peak_tflops": r2["roofline"]["peak"], "roofline_frac": r2["roofline"]["frac"],
+                 "roofline_frac_executed": r2["roofline"]["frac_executed"]}
+            if prec != "fp32":
+                e["psnr_vs_fp32_path_db"], e["psnr_coarse_vs_fp32_path_db"] = psnr_vs_fp32_path(wl, prec, device, rend2, net2, rays2)
+            sec.append(e)
             del net2, rend2, rays2
             torch.cuda.empty_cache()
         out["secondary"] = sec

@@ -316,9 +316,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 // LDS-DMA from C++ (global_load_lds_*): inline asm so that hipcc neither counts these loads in its own vmcnt bookkeeping
 // nor drains them before barriers / ds_reads; they are retired by the counted s_waitcnt of the asm blocks
 // (cdna_hip_programming.md §5.7).  M0 (the LDS destination base) is compiler-reserved, so a statement saves, sets and
-// restores it — and it holds M0 STEADY over all the DMAs it issues, with wait states before the restore: a statement per
-// DMA that rewrote M0 right behind the instruction returned run-to-run different results on an idle chip (the DMA could
-// pick up the restored / the next statement's M0).  Offsets apply to the global AND the LDS address.
+// restores it.  A piece reads M0 when it ISSUES (measured: tools/dev/ubench/waw_ubench.hip part C — M0 rewritten in the
+// next instruction, with or without older loads queued, and every byte still lands at the original destination), so the
+// restore may follow the last piece directly; `s_mov m0` -> piece needs its one documented wait state.  (Round 2 blamed
+// M0 for wrong results of a one-statement-per-piece variant; that was the statement-entry hazard of DESIGN.md 4.1.)
+// These statements write no VGPR, so rule R1 of tools/gen_resblock_asm.py does not apply to them.  Offsets apply to the
+// global AND the LDS address.
 //
 // One stage of the weight ring (only the first three stages are issued from here; the steady state lives in
 // resblock_asm.inc): lane l moves 4 x 16 B from g_base + lane_off + 1024 q to LDS lds_dst + 1024 q + 16 l.
@@ -327,7 +330,7 @@ __device__ __forceinline__ void glds_stage(const char* g_base /* wave-uniform */
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
 // 4 KiB of a wave's own workspace data back into LDS (the cached lin_z images): as glds_stage, but through the L2 — the lines
@@ -337,7 +340,7 @@ __device__ __forceinline__ void glds_stage_l2(const char* g_base /* wave-uniform
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:2048 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 sc1\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(g_base), "s"(lds_dst) : "memory");
 }
 
 // Per-lane-source LDS-DMA (a gather): fetches the NEXT tile's rays / sample positions a whole tile ahead of their use,
@@ -348,20 +351,20 @@ __device__ __forceinline__ void glds_gather_ray(const float* pr, const char* pz_
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "v"(pz_m1024), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "v"(pz_m1024), "s"(lds_dst) : "memory");
 }
 // the two halves of glds_gather_ray on their own (positions generated in the kernel / rays generated from a camera)
 __device__ __forceinline__ void glds_gather_ray_only(const float* pr, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(pr), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void glds_gather_z_only(const char* pz_m1024, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dword %1, off offset:1024\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pz_m1024), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(pz_m1024), "s"(lds_dst) : "memory");
 }
 // Explicit points: lane l moves the three components of its 12-byte record to dst + 256 k + 4 l (p = &record[0]).
 __device__ __forceinline__ void glds_gather_xyz(const char* p, uint32_t lds_dst) {
@@ -370,7 +373,7 @@ __device__ __forceinline__ void glds_gather_xyz(const char* p, uint32_t lds_dst)
     const char* p2 = p + 8 - 512;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
                  "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off offset:256\n\tglobal_load_lds_dword %3, off offset:512\n\t"
-                 "s_nop 7\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "v"(p1), "v"(p2), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "v"(p1), "v"(p2), "s"(lds_dst) : "memory");
 }
 
 // Diagnostic build only (-DPNR_STAMPS): per-section shader-cycle sums, never part of the product library.

@@ -175,6 +175,8 @@ class PixelNeRFNet(torch.nn.Module):
         return (mp.data_ptr(), mp._version, tuple(mp.shape), int(self.num_views_per_obj), len(self.encoder.level_maps()))
 
     def _build_mlp_struct(self, mlp, precision, views=None):
+        if mlp.n_blocks > N.PNR_MAX_BLOCKS:
+            raise ValueError(f"ResnetFC with {mlp.n_blocks} blocks: the native library holds at most {N.PNR_MAX_BLOCKS}")
         m = N.pnr_mlp()
         m.d_in, m.d_latent, m.d_hidden, m.d_out = mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out
         m.n_blocks, m.combine_layer, m.combine_type = mlp.n_blocks, mlp.combine_layer, N.COMBINE[mlp.combine_type]
@@ -200,6 +202,7 @@ class PixelNeRFNet(torch.nn.Module):
                 if proj_bytes:
                     mp = self.encoder.level_maps()[-1]          # the projected (last) level
                     lat_key = (mp.data_ptr(), mp._version, tuple(mp.shape))
+                    keep.append(mp)       # the cached struct keeps the map alive: its address cannot be reused under the same key
             key = ("mlp", id(mlp), precision, tuple((p.data_ptr(), p._version) for p in mlp.parameters()), lat_key)
             packed = self._pack_cache.get(key)
             if packed is None:

@@ -211,10 +211,14 @@ def _psnr(a, b):
 # same way).  That makes the end-to-end fine PSNR a heavy-tailed quantity, not a precision measure: over shapes x seeds x
 # weight streams it spreads 41.9 .. 72 dB in bf16 and 54 .. 85 dB in fp16 (tools/dev/e2e_fine_floor.py), the projected
 # and the general stream trading places by +-3 dB from seed to seed.  The precision statement for the fine pass is the
-# one at INJECTED fp32 sample positions (the bound above); end to end the tests hold a sanity floor of 40 dB.
+# one at INJECTED fp32 sample positions (the bound above, also checked against the reference's own fine pass in
+# test_mfma_matches_reference).  End to end:
+#   fp16: >= 50 dB — SURVEY §8(c)'s adopted bound holds end to end as well (measured minimum 54 dB);
+#   bf16: >= 40 dB — BELOW the §8(c) bound, bf16 only: a reported sanity floor under the measured spread (41.9 dB minimum),
+#         not a precision claim; bf16 is the dtype BASELINE.json names for cfg 2, fp16 is what precision="auto" selects.
 BF16_FLOOR_DB, FP16_FLOOR_DB = 42.4, 58.0
 FLOOR_DB = {"bf16": BF16_FLOOR_DB, "fp16": FP16_FLOOR_DB}
-FINE_E2E_FLOOR_DB = 40.0
+FINE_E2E_FLOOR_DB = {"bf16": 40.0, "fp16": 50.0}
 
 
 @pytest.mark.parametrize("prec,floor_pts,floor_px", [("bf16", 52.0, BF16_FLOOR_DB), ("fp16", 68.0, FP16_FLOOR_DB)])
@@ -233,11 +237,24 @@ def test_mfma_matches_reference(name, prec, floor_pts, floor_px):
         assert rel.max() <= (0.25 if prec == "bf16" else 0.05), tag          # sigma logits are x20 in the fixtures
     out = rend(net, _dev(fx["rays"]), want_weights=True)
     for lvl in levels:
-        assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= (floor_px if lvl == "coarse" else FINE_E2E_FLOOR_DB), lvl
+        assert _psnr(out[lvl].rgb.cpu(), fx[f"{lvl}_rgb"]) >= (floor_px if lvl == "coarse" else FINE_E2E_FLOOR_DB[prec]), lvl
         # fine pass: its sample positions are drawn from the LOW-PRECISION coarse weights/depth, so a sample can land in
         # a neighbouring bin and move one ray's weights discontinuously (SURVEY §8c caveat) — looser bound there
         tol_w = {("bf16", "coarse"): 0.05, ("bf16", "fine"): 0.15, ("fp16", "coarse"): 0.01, ("fp16", "fine"): 0.03}[(prec, lvl)]
         assert maxdiff(out[lvl].weights.cpu(), fx[f"{lvl}_weights"]) <= tol_w, lvl
+    if spec["Kf"] > 0:
+        # the fine pass at the REFERENCE's own sample positions ("compare fine pass with z_samp injected"): the
+        # reference's fine points through this precision's fine MLP, composited by the stage kernel, against the
+        # reference's fine pixels — the stated bound, no resampling in between.  z = (p - o) . d for unit d.
+        rays = _dev(fx["rays"]).reshape(-1, 8)
+        K = spec["Kc"] + spec["Kf"]
+        xyz = _dev(fx["pts_xyz_fine"]).reshape(rays.shape[0], K, 3)
+        z = ((xyz - rays[:, None, :3]) * rays[:, None, 3:6]).sum(-1).contiguous()
+        _, rgb_ref, _ = rend._composite_native(rays, z, _dev(fx["pts_out_fine"]).reshape(-1, K, 4).contiguous())
+        assert maxdiff(rgb_ref.cpu(), fx["fine_rgb"].reshape(-1, 3)) <= 1e-4        # the injected route reproduces the reference
+        pts = net(_dev(fx["pts_xyz_fine"]), coarse=False, viewdirs=_dev(fx["pts_dirs_fine"])).reshape(-1, K, 4).contiguous()
+        _, rgb_inj, _ = rend._composite_native(rays, z, pts)
+        assert _psnr(rgb_inj.cpu(), fx["fine_rgb"].reshape(-1, 3)) >= floor_px, "fine pass at the reference's sample positions"
 
 
 @pytest.mark.parametrize("prec,floor", [("bf16", 50.0), ("fp16", 65.0)])
@@ -305,7 +322,7 @@ def test_projected_stream_matches_general_path(prec, floor, floor_self, lat, ima
         assert _psnr(outs["proj"][lvl].rgb.cpu(), ref) >= floor
         assert _psnr(outs["gen"][lvl].rgb.cpu(), ref) >= floor
         assert _psnr(outs["proj"][lvl].rgb.cpu(), outs["gen"][lvl].rgb.cpu()) >= floor_self
-    assert _psnr(outs["proj"].fine.rgb.cpu(), outs["fp32"].fine.rgb.cpu()) >= FINE_E2E_FLOOR_DB
+    assert _psnr(outs["proj"].fine.rgb.cpu(), outs["fp32"].fine.rgb.cpu()) >= FINE_E2E_FLOOR_DB[prec]
     # re-encoding (new latent) must re-pack: same weights, different map -> different output, still right
     net = build_net(spec, poses, "cuda", prec)
     rend = build_renderer(spec); rend.forced_seed = 7
@@ -417,7 +434,7 @@ def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv, comb):
         assert _psnr(outs[p][2], outs["fp32"][2]) >= FLOOR_DB[p], (p, "coarse")
         assert _psnr(fine_fixed[p], fine_fixed["fp32"]) >= FLOOR_DB[p], (p, "fine pass at the fp32 sample positions")
         # end to end the fine pass resamples from the low-precision coarse weights (bins can flip): sanity floor only
-        assert _psnr(outs[p][0], outs["fp32"][0]) >= FINE_E2E_FLOOR_DB, (p, "fine, end to end")
+        assert _psnr(outs[p][0], outs["fp32"][0]) >= FINE_E2E_FLOOR_DB[p], (p, "fine, end to end")
 
 
 def test_render_image_from_camera_equals_forward_on_host_rays():
@@ -841,3 +858,84 @@ def test_full_dtu_frame_at_baseline_size():
         parts.append(rend(net, rays[None, lo:hi]).coarse.rgb[0])
     rend.ray_index_base = 0
     assert torch.equal(torch.cat(parts), ref.coarse.rgb[0])
+
+
+# ----------------------------------------------------------------------------- the fused kernel's shape space
+# make_layout (csrc/point_mfma.hip) accepts n_blocks 1..8, any combine_layer, d_latent in {256, 512, 768, 1024}: every
+# corner below either renders within the stated bound of the ORACLE (reference resnetfc.py:128-158,203-234 restated for
+# any n_blocks / combine_layer) or is refused with PNR_E_UNSUPPORTED before anything is launched.
+_SHAPES = [
+    # n_blocks, combine_layer, NS, latent levels, project_latent
+    (5, 0, 1, [(256, 8, 8)], True),                                          # no lin_z block at all (nb1 == 0)
+    (5, 5, 1, [(256, 8, 8)], True),                                          # every block has lin_z, none behind it (projected)
+    (5, 5, 1, [(256, 8, 8)], False),                                         # the same on the general stream
+    (5, 1000, 1, [(256, 19, 25)], True),                                     # the class default combine_layer, map too large to project
+    (3, 1, 2, [(256, 8, 8)], True),
+    (8, 3, 3, [(256, 6, 6)], True),
+    (8, 3, 3, [(256, 6, 6)], False),
+    (1, 1, 1, [(256, 8, 8)], True),
+    (2, 1, 2, [(256, 8, 8)], False),
+    (4, 2, 1, [(64, 16, 16), (64, 16, 16), (128, 8, 8), (256, 4, 4)], True),   # d_latent 512, last level projected
+    (5, 3, 2, [(512, 8, 8), (256, 4, 4)], True),                             # d_latent 768: two gathered groups + projection
+    (5, 3, 2, [(256, 8, 8), (256, 8, 8), (256, 19, 25)], True),              # d_latent 768, three gathered groups
+    (3, 2, 1, [(256, 8, 8), (256, 8, 8), (256, 8, 8), (256, 8, 8)], False),  # d_latent 1024
+]
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("n_blocks,combine_layer,NS,lat,proj", _SHAPES)
+def test_fused_kernel_shape_space(n_blocks, combine_layer, NS, lat, proj, prec):
+    from hip_util import build_net, build_renderer
+    from oracle import pixelnerf_oracle as orc
+    import golden_util as gu
+    spec = dict(gu.CASES["full_ns1"])
+    spec.update(n_blocks=n_blocks, combine_layer=combine_layer, NS=NS, lat=lat, N=150, Kc=16, Kf=8, Kfd=4,
+                seed=300 + 7 * n_blocks + combine_layer % 11 + NS, use_code_viewdirs=len(lat) == 4)
+    rays_np, poses = gu.make_inputs(spec)
+    g = torch.Generator().manual_seed(spec["seed"])
+    n, n_imp = spec["N"], spec["Kf"] - spec["Kfd"]
+    noise = dict(noise_c=torch.rand(n, spec["Kc"], generator=g), u=torch.rand(n, n_imp, generator=g),
+                 r=torch.rand(n, n_imp, generator=g), g=torch.randn(n, spec["Kfd"], generator=g))
+    W, H = spec["image"]
+    cam = orc.encode_cameras(torch.from_numpy(poses), spec["focal"], None, W, H)
+    sd = {w: {k: torch.from_numpy(v) for k, v in gu.make_mlp_state(spec, w).items()} for w in ("coarse", "fine")}
+    with torch.no_grad():
+        ref = orc.render(sd["coarse"], sd["fine"], cam, [torch.from_numpy(x) for x in gu.make_latents(spec)],
+                         torch.from_numpy(rays_np), NS, spec["Kc"], spec["Kf"], spec["Kfd"], spec["depth_std"],
+                         spec["white_bkgd"], spec["lindisp"], noise, use_code_viewdirs=spec["use_code_viewdirs"],
+                         n_blocks=n_blocks, combine_layer=combine_layer, combine_type=spec["combine_type"])
+    rays = torch.from_numpy(rays_np).cuda()
+    outs = {}
+    for p in ("fp32", prec):
+        net = build_net(spec, poses, "cuda", p)
+        net.project_latent = proj
+        assert net.resolved_precision(net.mlp_coarse, net.mlp_fine) == p
+        rend = build_renderer(spec)
+        rend.fixed_noise = {k: v.cuda() for k, v in noise.items()}
+        outs[p] = rend(net, rays, want_weights=True)
+    # the fp32 HIP path on this shape is pinned to the oracle like the fixtures pin it on the shipped shape
+    for lvl in ("coarse", "fine"):
+        assert maxdiff(outs["fp32"][lvl].rgb.cpu(), ref[lvl]["rgb"]) <= 1e-4, lvl
+        # per-sample weights: sigma is O(80) in these synthetic networks, so alpha = 1 - exp(-delta sigma) carries the fp32
+        # summation-order difference of the last layer at a few 1e-4 (measured 1.4e-4); a flipped bin would show as ~1e-1
+        assert maxdiff(outs["fp32"][lvl].weights.cpu(), ref[lvl]["weights"]) <= 4e-4, lvl
+    assert _psnr(outs[prec].coarse.rgb.cpu(), ref["coarse"]["rgb"]) >= FLOOR_DB[prec]
+    assert _psnr(outs[prec].fine.rgb.cpu(), ref["fine"]["rgb"]) >= FINE_E2E_FLOOR_DB[prec]
+    assert not torch.isnan(outs[prec].fine.rgb).any()
+
+
+@pytest.mark.parametrize("n_blocks,combine_layer,NS,lat", [
+    (5, 0, 2, [(256, 8, 8)]),                       # view reduction in front of the first block: nothing per view to run
+    (3, 5, 2, [(256, 8, 8)]),                       # reduction behind the last block: the reference returns NS x the rows
+    (9, 3, 1, [(256, 8, 8)]),                       # more blocks than the bias table holds
+])
+def test_fused_kernel_refuses_what_it_does_not_run(n_blocks, combine_layer, NS, lat):
+    from hip_util import build_net, build_renderer
+    import golden_util as gu
+    spec = dict(gu.CASES["full_ns1"])
+    spec.update(n_blocks=n_blocks, combine_layer=combine_layer, NS=NS, lat=lat, N=8, Kf=0, Kfd=0)
+    rays_np, poses = gu.make_inputs(spec)
+    net = build_net(spec, poses, "cuda", "fp16")
+    with pytest.raises((ValueError, RuntimeError)):
+        build_renderer(spec)(net, torch.from_numpy(rays_np).cuda())
+    torch.cuda.synchronize()

@@ -1,6 +1,7 @@
 """Diagnostic (GPU box): run-to-run determinism and parity of the fp16 / bf16 kernels vs the fp32 path in rays mode — the script
-behind the statement-entry drain evidence of DESIGN.md §4.1 (tools/dev/build_variant.sh bad "noentrydrain" builds the failing library, ... bad_a "noentrydrain drainA" the
-repaired one; run with PNR_LIB=tools/dev/libpnr_<NAME>.so)."""
+behind round 2's statement-entry experiments.  The cause is known now (DESIGN.md 4.1 "Statement-entry rule",
+profiles/r03_entry_hazard_isa_excerpt.txt: a pending compiler reload landing in a register the statement had already written); the
+generator enforces the entry guard, so there is no failing variant to build any more.  Kept as a determinism check for PNR_LIB builds."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -29,6 +29,21 @@ Contract with k_point_mfma:
     ld_slot, ld_rep, ld_wrap); then per block the inputs listed at each generator function.
   * entry: the next stage to consume is published, DMA of the two stages after it is in flight; exit: all LDS reads
     drained, accumulators readable, cursor advanced.
+Statement rules (audited by main() on the generated text, see audit_statement):
+  R1 entry   hipcc does NOT order its own pending loads against the registers a statement merely CLOBBERS: SIInsertWaitcnts
+             skips the implicit defs of a memory-touching INLINEASM, and the hardware has no interlock — a scratch reload
+             (or any VMEM / LDS / scalar load) still in flight lands AFTER the statement's own write of that register and
+             wins.  (Round 2: `scratch_load_dwordx4 v[8:11]` pending on the path into the resblock statement zeroed its ring
+             read bases v10 / v11, fp16 frame only; DESIGN.md 4.1, profiles/r03_entry_hazard_isa_excerpt.txt.)  So every
+             statement that writes a clobbered VGPR opens with `s_waitcnt vmcnt(0)` + `s_waitcnt lgkmcnt(0)` BEFORE the first
+             such write.  The LDS-DMA pieces of the previous statement are drained by it as well (0.1 %: they are two
+             stages old).
+  R2 exit    nothing that writes a register is pending at the end: the last LDS read is behind an lgkmcnt(0), the last
+             register load behind a vmcnt(0).  LDS-DMA pieces (no register destination) may stay in flight.
+  R3 M0      an LDS-DMA reads M0 when it ISSUES: rewriting M0 in the very next instruction, behind a busy VMEM queue or
+             not, still lands every byte at the original destination (tools/dev/ubench/waw_ubench.hip part C,
+             profiles/r03_waw_ubench.txt) — so M0 need not be held behind a piece.  The other direction is a documented
+             hazard: `s_mov_b32 m0` -> LDS-DMA needs one wait state (s_nop 0).
 Registers used inside (all declared clobbered): v10-13 slot read bases, v14 address temp, v15 DMA lane offset, v16-23 B pair of the
 x-stages, v40-55 / v72-87 the two chunk accumulators (VGPR-form MFMA), v44-51 next B pair (x-stages), v60-67 relu(h)
 fragments, v68-71 temps, v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 k-steps x 2 column groups x 4),
@@ -38,7 +53,7 @@ import os
 import re
 
 # timing experiments only (results are garbage): nobarrier, nodma, nowait, nosnap, dma1, dmaearly, dmaplain, dmaquarter;
-# hazard experiments: fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA, noentrydrain
+# hazard experiments of round 2 (kept for the record, all explained by rule R1): fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA
 DIAG = os.environ.get("PNR_ASM_DIAG", "")
 
 
@@ -189,19 +204,16 @@ class Emit:
             self.ds_read(f"A{i}", f"ds_read_b128 {A(i)}, {base} offset:{i * 1024}")
 
 
+def entry_guard(e):
+    """Rule R1: before the statement writes any register it only declares clobbered.  lgkmcnt(0) also covers hipcc's scalar
+    (kernel-argument) loads and LDS accesses: SMEM returns out of order and every later wait is a COUNTED lgkmcnt(N)."""
+    e("s_waitcnt vmcnt(0)")
+    e("s_waitcnt lgkmcnt(0)")
+
+
 def setup_cursor(E, cfg, stream):
     e = E.e
-    # hipcc may have a scalar (kernel-argument) load or an LDS access of its own in flight when the statement starts: both
-    # count in lgkmcnt, SMEM returns out of order, and every wait below is a COUNTED lgkmcnt(N) — drain them first
-    e("s_waitcnt lgkmcnt(0)")
-    # ... and start with no LDS-DMA piece of the previous statement in flight.  Measured (tools/dev/entry_drain_repro.py, fp16 build,
-    # 3 .. 250 workgroups): without this wait a statement that OPENS with x-stages while the previous statement's last two
-    # stages of pieces are still landing returns run-to-run different results (30 dB); vmcnt(0) here, or a 256-cycle
-    # s_sleep, makes them exact and repeatable, while vmcnt(4), a barrier, vmcnt(0) / lgkmcnt(0) at every stage INSIDE the
-    # statements, or a drain behind the x-stages do not.  It costs 0.1 % (the pieces are two stages old).  The mechanism is
-    # not identified; DESIGN.md §8 lists what was ruled out.
-    if "noentrydrain" not in DIAG:                          # PNR_ASM_DIAG=noentrydrain: the build WITHOUT this wait
-        e("s_waitcnt vmcnt(0)")
+    entry_guard(e)
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
     e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
@@ -581,8 +593,8 @@ def gen_linout(dt):
 def gen_viewspill():
     """Park this view's residual stream: the 256 accumulator registers -> workspace slot, float4 index (t*4+q)*64 + lane
     (layout-agnostic: the reduce reads the same registers back).  Operands: %0-%15 x tiles (pinned), %16 slot base (s64),
-    %17 lane*16 (v).  Hazards: MFMA write -> VMEM read of the AGPR (entry s_nop); store data -> overwrite of the source
-    AGPRs is covered by the vmcnt(0) every tile-writing statement opens with."""
+    %17 lane*16 (v).  Writes no VGPR (rule R1 does not apply; the audit checks that).  Hazard: MFMA write -> VMEM read of the
+    AGPR (entry s_nop)."""
     L = []
     e = L.append
     e("s_nop 15")
@@ -593,8 +605,10 @@ def gen_viewspill():
             e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
         e("s_add_u32 s24, s24, 0x1000")
         e("s_addc_u32 s25, s25, 0")
-    # No wait here: the tiles are dead until the next view's LIN_IN statement redefines them, and every statement that
-    # writes them opens with s_waitcnt vmcnt(0) (setup_cursor) — the 64 stores retire behind the next view's prologue.
+    # No vmcnt wait here: a store has read its data registers two wait states after it issued (the s_nop below covers the
+    # last one; the tiles are next written by the following view's LIN_IN MFMAs anyway), and the slot is not read before
+    # the reduce — whose entry guard drains the stores.  The 64 stores retire behind the next view's prologue.
+    e("s_nop 1")
     return L
 
 
@@ -629,6 +643,7 @@ def gen_viewreduce():
                     e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
                 e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
 
+    entry_guard(e)                                           # rule R1: the passes write v68-71 / v96-255
     e("s_nop 15")
     e("s_nop 15")
     e("s_mov_b64 s[26:27], %16")
@@ -660,6 +675,79 @@ def gen_viewreduce():
     e("6:")
     e("s_nop 7")
     return L
+
+
+M0_HOLD = 0        # instructions an LDS-DMA needs before the next write of M0: none, it reads M0 at issue (rule R3)
+
+
+def _vdest(line):
+    """Physical VGPRs (clobbered registers, named literally) the instruction writes; AGPRs are statement operands."""
+    m = re.match(r"\s*([a-z_0-9]+)\s+(.*)", line)
+    if not m:
+        return []
+    op, rest = m.group(1), m.group(2)
+    writes = (op.startswith("v_") and not op.startswith("v_cmp") and not op.startswith("v_accvgpr_write")) or \
+        op.startswith("ds_read") or (op.startswith("global_load_dword") and not op.startswith("global_load_lds"))
+    if not writes:
+        return []
+    d = rest.split(",")[0].strip()
+    m1 = re.fullmatch(r"v(\d+)", d)
+    m2 = re.fullmatch(r"v\[(\d+):(\d+)\]", d)
+    if m1:
+        return [int(m1.group(1))]
+    if m2:
+        return list(range(int(m2.group(1)), int(m2.group(2)) + 1))
+    return []                                                # %N operand or an AGPR
+
+
+def audit_statement(name, lines):
+    """Rules R1-R3 of the header on the final text of one statement (straight-line scan: branches only skip forward or loop
+    over stage bodies that satisfy the rules themselves)."""
+    seen_vm = seen_lgkm = False
+    first_write = None
+    for i, l in enumerate(lines):
+        if l.startswith("s_waitcnt") and "vmcnt(0)" in l:
+            seen_vm = True
+        if l.startswith("s_waitcnt") and "lgkmcnt(0)" in l:
+            seen_lgkm = True
+        if _vdest(l):
+            first_write = i
+            break
+    if first_write is not None:
+        assert seen_vm and seen_lgkm, f"{name}: R1 — '{lines[first_write]}' writes a clobbered VGPR before the entry guard"
+    # R2: the last register-writing LDS read / global load is followed by a full wait of its counter
+    last = {"lgkm": None, "vm": None}
+    for i, l in enumerate(lines):
+        if l.startswith("ds_read"):
+            last["lgkm"] = i
+        if l.startswith("global_load_dword") and _vdest(l):
+            last["vm"] = i
+    if last["lgkm"] is not None:
+        assert any(l.startswith("s_waitcnt") and "lgkmcnt(0)" in l for l in lines[last["lgkm"]:]), f"{name}: R2 — LDS read pending at exit"
+    if last["vm"] is not None:
+        assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in lines[last["vm"]:]), f"{name}: R2 — register load pending at exit"
+    # R3: M0 writes vs LDS-DMA
+    for i, l in enumerate(lines):
+        if l.startswith("global_load_lds"):
+            # the nearest M0 write above it must be >= 1 wait state away
+            for k in range(i - 1, -1, -1):
+                if lines[k].startswith("s_mov_b32 m0"):
+                    assert k <= i - 2, f"{name}: R3 — no wait state between '{lines[k]}' and the DMA"
+                    break
+                if lines[k].startswith("global_load_lds") or lines[k].endswith(":"):
+                    break
+            for k in range(i + 1, min(i + 1 + M0_HOLD, len(lines))):
+                assert not lines[k].startswith("s_mov_b32 m0"), f"{name}: R3 — M0 rewritten {k - i} instruction(s) behind a DMA"
+
+
+def audit_all(path):
+    text = open(path).read()
+    n = 0
+    for m in re.finditer(r"#define (PNR_\w+_ASM\w*) \\\n((?:    \".*\\n\\t\" \\\n)+)", text):
+        lines = re.findall(r'    "(.*)\\n\\t" \\', m.group(2))
+        audit_statement(m.group(1), lines)
+        n += 1
+    assert n == 8, f"audited {n} statements, expected 8"
 
 
 def main():
@@ -697,6 +785,7 @@ def main():
         clob = ["memory", "scc", "vcc"] + [f"v{i}" for i in list(range(10, 24)) + list(range(40, 56)) + list(range(60, 88)) + list(range(96, 256))] \
             + [f"s{i}" for i in list(range(20, 32)) + list(range(33, 44))]
         f.write("#define PNR_RESBLOCK_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+    audit_all(out)
     # audit: every physical v/s register the text names must be declared clobbered (operands are %N references)
     body = open(out).read()
     body = body[:body.index("#define PNR_RESBLOCK_CLOBBERS")]
