@@ -132,8 +132,10 @@ def build(workload, precision, device, rank_rays_scale=1, seed=0):
                 focal=w["focal"], N=0, Kc=w["Kc"], Kf=w["Kf"], Kfd=w["Kfd"], depth_std=0.01, lindisp=w["lindisp"],
                 white_bkgd=w["white"], use_code_viewdirs=w["cv"], z_near=w["z"][0], z_far=w["z"][1], radius=w["radius"])
     poses = np.stack([gu.pose_spherical(30.0 * v, -20.0, w["radius"]) for v in range(w["NS"])])[None]
-    net = build_net(spec, poses, device, precision)
-    rend = build_renderer(spec, device)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # the renderer's constructor prints like the reference's (nerf.py:82-83); stdout carries the JSON line only
+        net = build_net(spec, poses, device, precision)
+        rend = build_renderer(spec, device)
     from pixel_nerf_multiscale_amd import util
     tgt = util.pose_spherical(75.0, -25.0, w["radius"])[None].to(device)
     rays = util.gen_rays(tgt, W_img, H_img, torch.tensor(w["focal"]), w["z"][0], w["z"][1]).reshape(1, -1, 8)

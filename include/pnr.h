@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PNR_VERSION 100          /* 0.1.0 */
+#define PNR_VERSION 101          /* 0.1.1: output strides, per-object ray index stride */
 #define PNR_MAX_LEVELS 5         /* encoder levels of a multi-scale latent (encoder.py:62-73) */
 #define PNR_MAX_BLOCKS 8         /* ResnetFC blocks (resnetfc.py:147) */
 
@@ -114,6 +114,11 @@ typedef struct pnr_noise {
     const float* u;              /* (N, Kf-Kfd)  U[0,1) */
     const float* r;              /* (N, Kf-Kfd)  U[0,1) */
     const float* g;              /* (N, Kfd)     N(0,1) */
+    /* Key of the in-kernel generator for a call that holds a RANGE of every object's rays (one rank's shard of an
+     * (SB, B, 8) batch cut along B, as nn.DataParallel(dim=1) cuts it, render/nerf.py:367-371): ray i of object o counts as
+     * global ray  ray_index_base + o * ray_index_obj_stride + i.  0 = objects follow each other (stride = rays_per_obj),
+     * which is what an unsharded call means; a shard passes base = first ray of its range, stride = B. */
+    int64_t ray_index_obj_stride;
 } pnr_noise;
 
 /* Outputs of NeRFRenderer.forward (render/nerf.py:278-303); any member may be NULL. */
@@ -130,6 +135,13 @@ typedef struct pnr_outputs {
      * launch (the dominant kernel), so a caller can time that kernel inside a whole-path call; NULL = off */
     void* ev_point_begin;
     void* ev_point_end;
+    /* Row strides in floats of the rgb / depth / weights outputs; 0 = dense (3, 1, Kc, Kc+Kf).  With strides the members
+     * above may point INTO one packed per-ray record — e.g. rgb at +0, depth at +3 of a (N, 4) buffer that is this rank's
+     * slice of an all_gather buffer — so a sharded frame is written where the collective reads it (no copies). */
+    int32_t rgb_stride;
+    int32_t depth_stride;
+    int32_t coarse_weights_stride;
+    int32_t fine_weights_stride;
 } pnr_outputs;
 
 int32_t pnr_version(void);

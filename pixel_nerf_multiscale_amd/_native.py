@@ -64,13 +64,14 @@ class pnr_mlp_grads(C.Structure):
 
 
 class pnr_noise(C.Structure):
-    _fields_ = [("noise_c", _fp), ("u", _fp), ("r", _fp), ("g", _fp)]
+    _fields_ = [("noise_c", _fp), ("u", _fp), ("r", _fp), ("g", _fp), ("ray_index_obj_stride", C.c_int64)]
 
 
 class pnr_outputs(C.Structure):
     _fields_ = [("coarse_rgb", _fp), ("coarse_depth", _fp), ("coarse_weights", _fp), ("fine_rgb", _fp),
                 ("fine_depth", _fp), ("fine_weights", _fp), ("z_coarse", _fp), ("z_fine", _fp),
-                ("ev_point_begin", _fp), ("ev_point_end", _fp)]
+                ("ev_point_begin", _fp), ("ev_point_end", _fp), ("rgb_stride", C.c_int32), ("depth_stride", C.c_int32),
+                ("coarse_weights_stride", C.c_int32), ("fine_weights_stride", C.c_int32)]
 
 
 # every symbol include/pnr.h declares: name -> (restype, argtypes)

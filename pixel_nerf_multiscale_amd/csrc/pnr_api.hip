@@ -14,7 +14,12 @@ int32_t index_latent_f32(const pnr_views* vw, const float* uv, int64_t N, int uv
 int32_t sample_fine_launch(const float* rays, float near_all, float far_all, const float* z_coarse, const float* weights,
                            const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
                            float depth_std, int32_t lindisp, const float* u, const float* r, const float* g, uint64_t seed,
-                           int64_t ray_index_base, float* z_out, void* stream);
+                           RayKey key, float* z_out, void* stream, int w_stride = 0, int d_stride = 0);
+int32_t sample_coarse_launch(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp, const float* noise_c,
+                             uint64_t seed, RayKey key, float* z_out, void* stream);
+int32_t composite_launch(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays, int32_t K,
+                         int32_t white_bkgd, float* weights_out, float* rgb_out, float* depth_out, int w_stride,
+                         int rgb_stride, int depth_stride, void* stream);
 // point_mfma.hip
 uint64_t point_mfma_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw);
 int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t n_points,
@@ -273,8 +278,18 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
     float* dep_c = outputs->coarse_depth ? outputs->coarse_depth : (float*)(base + cw.depth);
     void* pws = base + cw.point;
     uint64_t pws_bytes = workspace_bytes - (uint64_t)((char*)pws - (char*)workspace);
-    const pnr_noise nz = noise ? *noise : pnr_noise{nullptr, nullptr, nullptr, nullptr};
+    const pnr_noise nz = noise ? *noise : pnr_noise{nullptr, nullptr, nullptr, nullptr, 0};
     if (Kf > 0 && (!outputs->fine_rgb || !outputs->fine_depth)) return PNR_E_NULL;
+    // the generator's key (pnr_noise.ray_index_obj_stride) and the output row strides (pnr_outputs); the coarse-pass
+    // outputs that only live in the workspace are dense
+    if (nz.ray_index_obj_stride < 0 || (nz.ray_index_obj_stride != 0 && nz.ray_index_obj_stride < rays_per_obj)) return PNR_E_SHAPE;
+    const RayKey key{ray_index_base, nz.ray_index_obj_stride ? nz.ray_index_obj_stride - rays_per_obj : 0, rays_per_obj};
+    if (outputs->rgb_stride < 0 || outputs->depth_stride < 0 || outputs->coarse_weights_stride < 0 ||
+        outputs->fine_weights_stride < 0) return PNR_E_SHAPE;
+    const int s_rgb = outputs->rgb_stride ? outputs->rgb_stride : 3, s_dep = outputs->depth_stride ? outputs->depth_stride : 1;
+    const int s_rgb_c = outputs->coarse_rgb ? s_rgb : 3, s_dep_c = outputs->coarse_depth ? s_dep : 1;
+    const int s_w_c = (outputs->coarse_weights && outputs->coarse_weights_stride) ? outputs->coarse_weights_stride : Kc;
+    const int s_w_f = outputs->fine_weights_stride ? outputs->fine_weights_stride : Kt;
 
     if (params->precision != PNR_F32) {
         // The MFMA kernel renders a pass in ONE launch: rays from the camera (if any) and coarse positions generated in the tile
@@ -283,8 +298,9 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         // between two MFMA tiles).
         RayJob job{};
         job.on = 1; job.K = Kc; job.gen_z = 1; job.lindisp = params->lindisp; job.white_bkgd = params->white_bkgd;
-        job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.ray_base = ray_index_base;
+        job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.key = key;
         job.z_out = zc; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        job.rgb_stride = s_rgb_c; job.depth_stride = s_dep_c; job.w_stride = s_w_c;
         job.w_out = (Kf > 0 || outputs->coarse_weights) ? w_c : nullptr;      // only the resampling and the caller read them
         if (cam) { job.from_cam = 1; job.cam = *cam; job.pix0 = (int)pix0; }
         PointSrc src{rays, nullptr, Kc, nullptr, nullptr};
@@ -300,14 +316,16 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         const bool in_kernel = (uint64_t)(P2 + Kc + 2) * 4 <= 16384 && n_rays <= 2048;
         if (!in_kernel) {
             if ((rc = sample_fine_launch(rays, cam ? cam->zn : 0.f, cam ? cam->zf : 0.f, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd,
-                                         params->depth_std, params->lindisp, nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream)))
+                                         params->depth_std, params->lindisp, nz.u, nz.r, nz.g, seed, key, zf, stream, s_w_c, s_dep_c)))
                 return rc;
         }
         job.resample = in_kernel ? 1 : 0;
         job.fine = FineArgs{Kc, Kf - Kfd, Kfd, P2, params->lindisp, params->depth_std, nz.u, nz.r, nz.g, seed};
         job.zc = zc; job.wc = w_c; job.depth_c = dep_c; job.z_fine = zf;
+        job.wc_stride = s_w_c; job.dc_stride = s_dep_c;
         job.K = Kt; job.gen_z = 0; job.noise_c = nullptr; job.z_out = nullptr;
         job.w_out = outputs->fine_weights; job.rgb_out = outputs->fine_rgb; job.depth_out = outputs->fine_depth;
+        job.rgb_stride = s_rgb; job.depth_stride = s_dep; job.w_stride = s_w_f;
         PointSrc srcf{rays, zf, Kt, nullptr, nullptr};
         return point_mfma(params, fine ? fine : coarse, views, srcf, n_rays * Kt, rays_per_obj * Kt, rgbs, pws, pws_bytes, s, &job);
     }
@@ -323,22 +341,22 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         rays = rbuf;
     }
     // coarse pass (nerf.py:273-282)
-    if ((rc = pnr_sample_coarse(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, ray_index_base, zc, stream))) return rc;
+    if ((rc = sample_coarse_launch(rays, n_rays, Kc, params->lindisp, nz.noise_c, seed, key, zc, stream))) return rc;
     PointSrc src{rays, zc, Kc, nullptr, nullptr};
     if (outputs->ev_point_begin) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_begin, s));
     if ((rc = point_dispatch(params, coarse, views, src, n_rays * Kc, rays_per_obj * Kc, rgbs, pws, pws_bytes, s))) return rc;
     if (outputs->ev_point_end) PNR_HIP_CHECK(hipEventRecord((hipEvent_t)outputs->ev_point_end, s));
-    if ((rc = pnr_composite(rays, zc, rgbs, n_rays, Kc, params->white_bkgd, w_c, rgb_c, dep_c, stream))) return rc;
+    if ((rc = composite_launch(rays, zc, rgbs, n_rays, Kc, params->white_bkgd, w_c, rgb_c, dep_c, s_w_c, s_rgb_c, s_dep_c, stream))) return rc;
     if (Kf == 0) return PNR_OK;
 
     // fine pass (nerf.py:284-301); mlp_fine=None falls back to the coarse MLP (backup2:258)
-    if ((rc = pnr_sample_fine(rays, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
-                              nz.u, nz.r, nz.g, seed, ray_index_base, zf, stream))) return rc;
+    if ((rc = sample_fine_launch(rays, 0.f, 0.f, zc, w_c, dep_c, n_rays, Kc, Kf, Kfd, params->depth_std, params->lindisp,
+                                 nz.u, nz.r, nz.g, seed, key, zf, stream, s_w_c, s_dep_c))) return rc;
     PointSrc srcf{rays, zf, Kt, nullptr, nullptr};
     if ((rc = point_dispatch(params, fine ? fine : coarse, views, srcf, n_rays * Kt, rays_per_obj * Kt, rgbs, pws,
                              pws_bytes, s))) return rc;
-    return pnr_composite(rays, zf, rgbs, n_rays, Kt, params->white_bkgd, outputs->fine_weights, outputs->fine_rgb,
-                         outputs->fine_depth, stream);
+    return composite_launch(rays, zf, rgbs, n_rays, Kt, params->white_bkgd, outputs->fine_weights, outputs->fine_rgb,
+                            outputs->fine_depth, s_w_f, s_rgb, s_dep, stream);
 }
 
 extern "C" int32_t pnr_render(const pnr_params* params, const pnr_mlp* coarse, const pnr_mlp* fine,

@@ -45,6 +45,14 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 
 enum { DRAW_COARSE = 0, DRAW_U = 1, DRAW_R = 2, DRAW_G = 3 };
 
+// Global index of a call's local ray r (the generator's key; pnr_noise.ray_index_obj_stride in pnr.h): base + r for a call
+// whose objects follow each other, base + (r / rays_per_obj) * stride + r % rays_per_obj for a shard that holds a range of
+// every object's rays (extra = stride - rays_per_obj; the division only runs on that path).
+struct RayKey { int64_t base; int64_t extra; int64_t rays_per_obj; };
+__device__ __forceinline__ int64_t global_ray(const RayKey& k, int64_t r) {
+    return k.base + r + (k.extra != 0 ? (r / k.rays_per_obj) * k.extra : 0);
+}
+
 __device__ __forceinline__ float rng_uniform(uint64_t seed, int64_t ray, int draw, int idx) {
     u32x4 v = philox4x32(seed, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), (uint32_t)draw, (uint32_t)idx);
     return u01(v.x);
@@ -354,14 +362,16 @@ struct RayJob {
     int from_cam;                   // 1: ray r is pixel pix0 + r of `cam` (no ray tensor)
     int rays_per_wg;
     int64_t n_rays;
-    const float* noise_c; uint64_t seed; int64_t ray_base;
+    const float* noise_c; uint64_t seed; RayKey key;
     float* z_out; float* w_out; float* rgb_out; float* depth_out;      // w_out may be NULL
+    int rgb_stride, depth_stride, w_stride;                            // floats per ray (pnr_outputs strides; dense: 3, 1, K)
     RayCam cam; int pix0;
     // fine pass: the launch first resamples its own rays (sample_fine .. sort, nerf.py:120-161,285-295) from the coarse pass's
     // outputs into z_fine (= PointSrc.z of this launch), every workgroup for the rays it owns
     int resample;
     FineArgs fine;
     const float* zc; const float* wc; const float* depth_c;
+    int wc_stride, dc_stride;       // floats per ray of the coarse weights / depth the resampling reads (they may be strided outputs)
     float* z_fine;
 };
 

@@ -501,9 +501,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             const int64_t ray = ray_begin + lr;
             const float near = flag(a.job.from_cam) ? a.job.cam.zn : a.src.rays[ray * 8 + 6];
             const float far = flag(a.job.from_cam) ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
-            const float depth = f.n_dep > 0 ? a.job.depth_c[ray] : 0.f;
-            sample_fine_ray<false>(f, a.job.zc + ray * f.Kc, a.job.wc ? a.job.wc + ray * f.Kc : nullptr, depth, near, far, ray,
-                                   a.job.ray_base + ray, true, cdf, buf, a.job.z_fine + ray * Kt, lane, wave_sync);
+            const float depth = f.n_dep > 0 ? a.job.depth_c[ray * a.job.dc_stride] : 0.f;
+            sample_fine_ray<false>(f, a.job.zc + ray * f.Kc, a.job.wc ? a.job.wc + ray * a.job.wc_stride : nullptr, depth, near, far, ray,
+                                   global_ray(a.job.key, ray), true, cdf, buf, a.job.z_fine + ray * Kt, lane, wave_sync);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -587,10 +587,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             const float far = flag(a.job.from_cam) ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
             const float* zr = (flag(a.job.gen_z) ? a.job.z_out : a.src.z) + ray * K;
             const float4 r = composite_ray<true>(zr, (const float4*)a.out + ray * K, K, far, a.job.white_bkgd,
-                                                 a.job.w_out ? a.job.w_out + ray * K : nullptr, lane);
+                                                 a.job.w_out ? a.job.w_out + ray * a.job.w_stride : nullptr, lane);
             if (lane == 0) {
-                a.job.rgb_out[ray * 3 + 0] = r.x; a.job.rgb_out[ray * 3 + 1] = r.y; a.job.rgb_out[ray * 3 + 2] = r.z;
-                a.job.depth_out[ray] = r.w;
+                float* po = a.job.rgb_out + ray * a.job.rgb_stride;
+                po[0] = r.x; po[1] = r.y; po[2] = r.z;
+                a.job.depth_out[ray * a.job.depth_stride] = r.w;
             }
         }
     };
@@ -789,7 +790,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                             const int k = li - lr * Kq;
                             const int64_t gp = p_begin + li;
                             const float u = flagp(a.job.noise_c) ? a.job.noise_c[gp]
-                                                          : rng_uniform(a.job.seed, a.job.ray_base + ray_begin + lr, DRAW_COARSE, k);
+                                                          : rng_uniform(a.job.seed, global_ray(a.job.key, ray_begin + lr), DRAW_COARSE, k);
                             const float t = fmaf(u, 1.0f / (float)Kq, linspace_k(k, Kq));
                             zz = z_from_t(t, near, far, a.job.lindisp);
                             if (v == 0 && g == 0 && in_range) a.job.z_out[gp] = zz;
@@ -845,6 +846,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 uvw[lane] = make_float4(pu[0], pv[0], pu[1], pv[1]);      // for the gather / tap image of this view's blocks
                 STAMP_ACC(1, st_t);
                 lin_in_stages();
+                STAMP_ACC(8, st_t);
                 if (flag(a.job.on) && v == 0 && tile > 0) {
                     // the rays the previous tile finished: every wave has been through the vmcnt(0) and the barriers of the
                     // LIN_IN statement since it stored that tile's outputs, so they are in the L2 for any wave to read
@@ -854,6 +856,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     upto = __builtin_amdgcn_readfirstlane((int)((uint32_t)(upto < n_loc ? upto : n_loc) / (uint32_t)Kc_q));
                     composite_rays(rays_done, upto);
                     rays_done = upto;
+                    STAMP_ACC(9, st_t);
                 }
                 if (a.proj && n_gather == 0) tap_image();          // fully projected: the image serves all blocks of this view
                 else if (!a.proj && n_gather == 1) gather(0, false);
@@ -869,7 +872,9 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 for (int grp = 0; grp < n_groups; ++grp) {
                     if (b == 0) gather(grp, true);
                     else restore(grp);
+                    STAMP_ACC(10, st_t);
                     x_stages(8);
+                    STAMP_ACC(11, st_t);
                 }
                 if (a.proj && n_gather > 0) tap_image();           // partial projection: the buffer was just used by the gather
                 else if (!a.proj && n_gather > 1) {
@@ -903,6 +908,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 const float4* slot = slot0 + (size_t)v * 4096;
                 const uint32_t lane16 = lane_id() * 16;
                 asm volatile(PNR_VIEWSPILL_ASM : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
+                STAMP_ACC(4, st_t);
             }
             view_pass();
             const int nm1 = a.NS - 1;
@@ -912,6 +918,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             const uint32_t lane16 = lane_id() * 16;
             asm volatile(PNR_VIEWREDUCE_ASM : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
                          : PNR_RESBLOCK_CLOBBERS);
+            STAMP_ACC(5, st_t);
         } else {
             view_pass();
         }

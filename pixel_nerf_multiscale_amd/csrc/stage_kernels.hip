@@ -7,14 +7,14 @@ namespace pnr {
 
 // ------------------------------------------------------------------ sample_coarse  (nerf.py:98-118): z_from_t / linspace_k in pnr_common.h
 __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, int Kc, int lindisp,
-                                const float* __restrict__ noise, uint64_t seed, int64_t ray_base,
+                                const float* __restrict__ noise, uint64_t seed, RayKey key,
                                 float* __restrict__ z_out) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rays * Kc) return;
     int64_t ray = idx / Kc;
     int k = (int)(idx % Kc);
     float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
-    float u = noise ? noise[idx] : rng_uniform(seed, ray_base + ray, DRAW_COARSE, k);
+    float u = noise ? noise[idx] : rng_uniform(seed, global_ray(key, ray), DRAW_COARSE, k);
     float t = fmaf(u, 1.0f / (float)Kc, linspace_k(k, Kc));
     z_out[idx] = z_from_t(t, near, far, lindisp);
 }
@@ -23,15 +23,17 @@ __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, 
 __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ rays, const float* __restrict__ z,
                                                    const float4* __restrict__ rgbs, int64_t n_rays, int K,
                                                    int white_bkgd, float* __restrict__ w_out,
-                                                   float* __restrict__ rgb_out, float* __restrict__ depth_out) {
+                                                   float* __restrict__ rgb_out, float* __restrict__ depth_out,
+                                                   int w_stride, int rgb_stride, int depth_stride /* floats per ray */) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= n_rays) return;                      // whole wave exits together
     const float4 r = composite_ray<false>(z + ray * K, rgbs + ray * K, K, rays[ray * 8 + 7], white_bkgd,
-                                          w_out ? w_out + ray * K : nullptr, lane);
+                                          w_out ? w_out + ray * w_stride : nullptr, lane);
     if (lane == 0) {
-        rgb_out[ray * 3 + 0] = r.x; rgb_out[ray * 3 + 1] = r.y; rgb_out[ray * 3 + 2] = r.z;
-        depth_out[ray] = r.w;
+        float* po = rgb_out + ray * rgb_stride;
+        po[0] = r.x; po[1] = r.y; po[2] = r.z;
+        depth_out[ray * depth_stride] = r.w;
     }
 }
 
@@ -41,8 +43,9 @@ __global__ void __launch_bounds__(256) k_sample_fine(
     const float* __restrict__ rays, const float* __restrict__ zc, const float* __restrict__ weights,
     const float* __restrict__ depth, int64_t n_rays, int Kc, int n_imp, int n_dep, float depth_std, int lindisp,
     const float* __restrict__ un, const float* __restrict__ rn, const float* __restrict__ gn,
-    uint64_t seed, int64_t ray_base, float* __restrict__ z_out, int P2 /* pow2 >= Kc+n_imp+n_dep */,
-    float near_all, float far_all /* the bounds of every ray when rays == NULL (rays of one camera) */) {
+    uint64_t seed, RayKey key, float* __restrict__ z_out, int P2 /* pow2 >= Kc+n_imp+n_dep */,
+    float near_all, float far_all /* the bounds of every ray when rays == NULL (rays of one camera) */,
+    int w_stride, int d_stride /* floats per ray of `weights` / `depth` */) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
@@ -51,9 +54,9 @@ __global__ void __launch_bounds__(256) k_sample_fine(
     float* buf = cdf + Kc + 2;                       // P2 entries
     const int64_t rr = live ? ray : 0;
     const FineArgs f{Kc, n_imp, n_dep, P2, lindisp, depth_std, un, rn, gn, seed};
-    sample_fine_ray<false>(f, zc + rr * Kc, weights ? weights + rr * Kc : nullptr, (live && n_dep > 0) ? depth[rr] : 0.f,
+    sample_fine_ray<false>(f, zc + rr * Kc, weights ? weights + rr * w_stride : nullptr, (live && n_dep > 0) ? depth[rr * d_stride] : 0.f,
                            !rays ? near_all : live ? rays[rr * 8 + 6] : 0.f, !rays ? far_all : live ? rays[rr * 8 + 7] : 0.f,
-                           rr, ray_base + rr, live, cdf, buf,
+                           rr, global_ray(key, rr), live, cdf, buf,
                            z_out + rr * (Kc + n_imp + n_dep), lane, [] { __syncthreads(); });
 }
 
@@ -74,30 +77,45 @@ __global__ void k_gen_rays(RayCam c, int64_t pix0, int64_t n, float* __restrict_
 using namespace pnr;
 
 
-extern "C" int32_t pnr_sample_coarse(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp,
-                                     const float* noise_c, uint64_t seed, int64_t ray_index_base,
-                                     float* z_out, void* stream) {
+namespace pnr {
+int32_t sample_coarse_launch(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp, const float* noise_c,
+                             uint64_t seed, RayKey key, float* z_out, void* stream) {
     if (!rays || !z_out) return PNR_E_NULL;
     if (n_rays < 0 || n_coarse <= 0) return PNR_E_SHAPE;
     if (n_rays == 0) return PNR_OK;
     int64_t tot = n_rays * n_coarse;
     hipLaunchKernelGGL(k_sample_coarse, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       rays, n_rays, n_coarse, lindisp, noise_c, seed, ray_index_base, z_out);
+                       rays, n_rays, n_coarse, lindisp, noise_c, seed, key, z_out);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
 }
 
-extern "C" int32_t pnr_composite(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays,
-                                 int32_t K, int32_t white_bkgd, float* weights_out, float* rgb_out,
-                                 float* depth_out, void* stream) {
+// strides in floats per ray (0 = dense)
+int32_t composite_launch(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays, int32_t K,
+                         int32_t white_bkgd, float* weights_out, float* rgb_out, float* depth_out, int w_stride,
+                         int rgb_stride, int depth_stride, void* stream) {
     if (!rays || !z || !rgbsigma || !rgb_out || !depth_out) return PNR_E_NULL;
     if (n_rays < 0 || K <= 0) return PNR_E_SHAPE;
     if (((uintptr_t)rgbsigma & 15) != 0) return PNR_E_ALIGN;
     if (n_rays == 0) return PNR_OK;
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       rays, z, (const float4*)rgbsigma, n_rays, K, white_bkgd, weights_out, rgb_out, depth_out);
+                       rays, z, (const float4*)rgbsigma, n_rays, K, white_bkgd, weights_out, rgb_out, depth_out,
+                       w_stride ? w_stride : K, rgb_stride ? rgb_stride : 3, depth_stride ? depth_stride : 1);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
+}
+}  // namespace pnr
+
+extern "C" int32_t pnr_sample_coarse(const float* rays, int64_t n_rays, int32_t n_coarse, int32_t lindisp,
+                                     const float* noise_c, uint64_t seed, int64_t ray_index_base,
+                                     float* z_out, void* stream) {
+    return sample_coarse_launch(rays, n_rays, n_coarse, lindisp, noise_c, seed, RayKey{ray_index_base, 0, 1}, z_out, stream);
+}
+
+extern "C" int32_t pnr_composite(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays,
+                                 int32_t K, int32_t white_bkgd, float* weights_out, float* rgb_out,
+                                 float* depth_out, void* stream) {
+    return composite_launch(rays, z, rgbsigma, n_rays, K, white_bkgd, weights_out, rgb_out, depth_out, 0, 0, 0, stream);
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -107,7 +125,7 @@ namespace pnr {
 int32_t sample_fine_launch(const float* rays, float near_all, float far_all, const float* z_coarse, const float* weights,
                            const float* depth, int64_t n_rays, int32_t n_coarse, int32_t n_fine, int32_t n_fine_depth,
                            float depth_std, int32_t lindisp, const float* u, const float* r, const float* g, uint64_t seed,
-                           int64_t ray_index_base, float* z_out, void* stream) {
+                           RayKey key, float* z_out, void* stream, int w_stride, int d_stride) {
     if (!z_coarse || !z_out) return PNR_E_NULL;
     if (n_rays < 0 || n_coarse <= 0 || n_fine < 0 || n_fine_depth < 0 || n_fine_depth > n_fine) return PNR_E_SHAPE;
     int n_imp = n_fine - n_fine_depth;
@@ -123,7 +141,7 @@ int32_t sample_fine_launch(const float* rays, float near_all, float far_all, con
         PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_sample_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_sample_fine, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, (hipStream_t)stream,
                        rays, z_coarse, weights, depth, n_rays, n_coarse, n_imp, n_fine_depth, depth_std, lindisp,
-                       u, r, g, seed, ray_index_base, z_out, P2, near_all, far_all);
+                       u, r, g, seed, key, z_out, P2, near_all, far_all, w_stride ? w_stride : n_coarse, d_stride ? d_stride : 1);
     PNR_LAUNCH_CHECK();
     return PNR_OK;
 }
@@ -136,7 +154,7 @@ extern "C" int32_t pnr_sample_fine(const float* rays, const float* z_coarse, con
                                    float* z_out, void* stream) {
     if (!rays) return PNR_E_NULL;
     return sample_fine_launch(rays, 0.f, 0.f, z_coarse, weights, depth, n_rays, n_coarse, n_fine, n_fine_depth, depth_std,
-                              lindisp, u, r, g, seed, ray_index_base, z_out, stream);
+                              lindisp, u, r, g, seed, RayKey{ray_index_base, 0, 1}, z_out, stream, 0, 0);
 }
 
 extern "C" int32_t pnr_gen_rays(const float* c2w, int32_t W, int32_t H, float fx, float fy, float cx, float cy,

@@ -2,10 +2,12 @@
 Multi-GPU rendering: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), replacing the
 reference's single-process nn.DataParallel(dim=1) (reference render/nerf.py:367-371, broken there: SURVEY D8).
 
-Rays are independent units, so a frame is cut into contiguous ray ranges, one per rank; every rank holds the
-same packed weights and latents (loaded / encoded locally), renders its range with the in-kernel noise keyed
-by the GLOBAL ray index, and ONE collective per frame — an all_gather of (rays/world, 4) fp32 [rgb, depth] —
-reassembles the pixels on every rank.  With the same seed the gathered frame is bit-identical to the 1-GPU frame.
+Rays are independent units, so a batch (SB, B, 8) is cut along B into contiguous ranges, one per rank (every object's
+rays alike, as DataParallel(dim=1) does); every rank holds the same packed weights and latents (loaded / encoded
+locally), renders its range with the in-kernel noise keyed by the ray's index in the UNSHARDED batch, and ONE collective
+per call — an in-place all_gather of (SB * B/world, 4) fp32 [rgb, depth] records that the render launch itself wrote into
+this rank's slice of the buffer — reassembles the pixels on every rank.  With the same seed the gathered batch is
+bit-identical to the 1-GPU one.  Training is data-parallel instead (one batch per rank, allreduce_gradients below).
 """
 import torch
 import torch.distributed as dist
@@ -27,12 +29,16 @@ def frame_seed(base_seed, frame_idx):
 
 
 class ShardedRenderer:
-    """render_shard(rays (1, n, 8), ray_index_base, seed) -> (rgb (1,n,3), depth (1,n)) is the per-rank renderer;
-    __call__(rays (1, B, 8)) returns the full (rgb (1,B,3), depth (1,B)) on every rank.  gather() is the general
-    form: any list of per-ray outputs, packed into one (rays/world, sum(widths)) fp32 message."""
+    """render_shard(rays (SB, n, 8), ray_index_base, seed[, obj_stride]) -> per-ray outputs of its range is the per-rank
+    renderer; __call__(rays (SB, B, 8)) returns the full (rgb (SB,B,3), depth (SB,B)) on every rank.  gather() is the
+    general form: any list of per-ray outputs, packed into one (SB * rays/world, sum(widths)) fp32 message.
+    render_into(rays, base, seed, obj_stride, out (SB, n, tot)) -> bool, when given and returning True, has written the
+    packed records straight into `out` — this rank's slice of the gather buffer — so the collective runs in place with
+    no copy before it (NeRFRenderer.forward_packed: the render launch writes them)."""
 
-    def __init__(self, render_shard, group=None, base_seed=None):
+    def __init__(self, render_shard, group=None, base_seed=None, render_into=None):
         self.render_shard = render_shard
+        self.render_into = render_into
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -49,49 +55,77 @@ class ShardedRenderer:
     @classmethod
     def for_model(cls, renderer, net, **kw):
         """Bind a NeRFRenderer + PixelNeRFNet (simple_output semantics: fine if using_fine else coarse)."""
-        def render_shard(rays, base, seed):
-            renderer.ray_index_base, renderer.forced_seed = base, seed
+        def keyed(base, seed, obj_stride):
+            renderer.ray_index_base, renderer.forced_seed, renderer.ray_index_obj_stride = base, seed, obj_stride
+
+        def render_shard(rays, base, seed, obj_stride=0):
+            keyed(base, seed, obj_stride)
             try:
                 out = renderer(net, rays)
             finally:
-                renderer.ray_index_base, renderer.forced_seed = 0, None
+                keyed(0, None, 0)
             lvl = out.fine if renderer.using_fine else out.coarse
             return lvl.rgb, lvl.depth
-        return cls(render_shard, **kw)
+
+        def render_into(rays, base, seed, obj_stride, out):
+            if not (hasattr(renderer, "forward_packed") and rays.is_cuda and hasattr(net, "wants_grad")):
+                return False
+            keyed(base, seed, obj_stride)
+            try:
+                renderer.forward_packed(net, rays, out, ("fine",) if renderer.using_fine else ("coarse",), False)
+            finally:
+                keyed(0, None, 0)
+            return True
+        return cls(render_shard, render_into=render_into, **kw)
 
     def gather(self, rays, widths):
-        """rays (1, B, 8); render_shard returns len(widths) tensors of (1, n, w) / (1, n) for its range.  ONE
-        all_gather of (ceil(B/world), sum(widths)) fp32; returns the full (1, B, w) / (1, B) tensors on every rank."""
-        assert rays.dim() == 3 and rays.shape[0] == 1, "sharded rendering takes one object per call: rays (1, B, 8)"
-        B = rays.shape[1]
+        """rays (SB, B, 8), cut along B: rank k renders rays[:, lo_k:hi_k] of EVERY object (nn.DataParallel(dim=1),
+        reference render/nerf.py:367-371) with the generator keyed by the rays' indices in the unsharded batch.  ONE
+        all_gather of (SB * ceil(B/world), sum(widths)) fp32 per rank, in place on the buffer the render launch wrote;
+        returns the full (SB, B, w) / (SB, B) tensors on every rank (views of the gathered buffer when SB == 1)."""
+        assert rays.dim() == 3, "rays (SB, B, 8)"
+        SB, B = rays.shape[0], rays.shape[1]
         lo, hi, per = shard_range(B, self.world, self.rank)
+        n = hi - lo
         seed = frame_seed(self.base_seed, self.frame_idx)
         self.frame_idx += 1
         tot = int(sum(widths))
-        pix = torch.zeros(per, tot, device=rays.device, dtype=torch.float32)
-        if hi > lo:
-            outs = self.render_shard(rays[:, lo:hi].contiguous(), lo, seed)
-            assert len(outs) == len(widths)
-            off = 0
-            for t, w in zip(outs, widths):
-                pix[: hi - lo, off:off + w] = t.reshape(hi - lo, w)
-                off += w
+        obj_stride = B if SB > 1 else 0
+        full = torch.empty(self.world, SB * per, tot, device=rays.device, dtype=torch.float32)
+        mine = full[self.rank]                                       # (SB * per, tot): rows [0, SB * n) are this rank's records
+        if n > 0:
+            shard = rays[:, lo:hi] if SB == 1 else rays[:, lo:hi].contiguous()
+            slab = mine[: SB * n].view(SB, n, tot)
+            if not (self.render_into is not None and self.render_into(shard, lo, seed, obj_stride, slab)):
+                outs = self.render_shard(shard.contiguous(), lo, seed) if obj_stride == 0 else \
+                    self.render_shard(shard.contiguous(), lo, seed, obj_stride)
+                assert len(outs) == len(widths)
+                off = 0
+                for t, w in zip(outs, widths):
+                    slab[..., off:off + w] = t.reshape(SB, n, w)
+                    off += w
         if self.world > 1:
-            if pix.is_cuda and dist.get_backend(self.group) != "nccl":
+            if full.is_cuda and dist.get_backend(self.group) != "nccl":
                 # a host-memory backend (gloo) under device tensors — rehearsing the multi-rank path with several ranks on
                 # one card, where RCCL refuses duplicate devices: the (small) message travels through the host
-                host = torch.empty(self.world * per, tot, dtype=torch.float32)
-                dist.all_gather_into_tensor(host, pix.cpu(), group=self.group)
+                host = torch.empty(self.world, SB * per, tot, dtype=torch.float32)
+                dist.all_gather_into_tensor(host.view(-1), mine.cpu().view(-1), group=self.group)
                 full = host.to(rays.device)
             else:
-                full = torch.empty(self.world * per, tot, device=rays.device, dtype=torch.float32)
-                dist.all_gather_into_tensor(full, pix, group=self.group)
+                dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=self.group)     # in place: input = output[rank]
+        if SB == 1:
+            recs = full.view(self.world * per, tot)[:B].unsqueeze(0)                            # (1, B, tot), a view
         else:
-            full = pix
-        full = full[:B]
+            # rank k's slab holds (SB, n_k, tot) in its first SB * n_k rows: stitch the ranges back along B (one copy)
+            parts = []
+            for k in range(self.world):
+                lo_k, hi_k, _ = shard_range(B, self.world, k)
+                if hi_k > lo_k:
+                    parts.append(full[k][: SB * (hi_k - lo_k)].view(SB, hi_k - lo_k, tot))
+            recs = torch.cat(parts, dim=1)
         res, off = [], 0
         for w in widths:
-            res.append(full[:, off:off + w].reshape(1, B, w) if w > 1 else full[:, off].reshape(1, B))
+            res.append(recs[..., off:off + w] if w > 1 else recs[..., off])
             off += w
         return res
 

@@ -32,45 +32,77 @@ class _RenderWrapper(torch.nn.Module):
 
 
 class _ShardedRenderWrapper(torch.nn.Module):
-    """The multi-GPU form of _RenderWrapper: same call signature and return structure, the frame's rays cut into one
-    contiguous range per rank of the process group (parallel.ShardedRenderer), ONE all_gather per call, the full
-    frame returned on every rank.  Replaces nn.DataParallel(wrapped, gpus, dim=1) of nerf.py:367-371."""
+    """The multi-GPU form of _RenderWrapper: same call signature and return structure, every object's rays cut into one
+    contiguous range per rank of the process group along dim 1 — as nn.DataParallel(wrapped, gpus, dim=1) of
+    nerf.py:367-371 cuts them, any SB — ONE all_gather per call, the full batch returned on every rank
+    (parallel.ShardedRenderer).  The render launch writes its pixels (and weights) straight into this rank's slice of the
+    gather buffer (pnr_outputs strides): no copies around the collective.
+    Differentiable calls (net.train() with autograd on: train/train.py:171,331 calls render_par(all_rays,
+    want_weights=True) under the same binding) are NOT sharded: an all_gather is not differentiable and every rank of a
+    data-parallel trainer has its own batch, so they run on the local _RenderWrapper path and the step hook is
+    parallel.allreduce_gradients(net.parameters()) before optimizer.step()."""
 
     def __init__(self, net, renderer, simple_output, group=None):
         super().__init__()
         from ..parallel import ShardedRenderer
         self.net, self.renderer, self.simple_output = net, renderer, simple_output
-        lvls = lambda: ("fine",) if (simple_output and renderer.using_fine) else \
-            (("coarse",) if simple_output else (("coarse", "fine") if renderer.using_fine else ("coarse",)))
-        self._levels = lvls
-
+        self.local = _RenderWrapper(net, renderer, simple_output)
         self._want_weights = False
+        self.sharded = ShardedRenderer(self._render_shard, group=group, render_into=self._render_into)
 
-        def render_shard(rays, base, seed):
-            renderer.ray_index_base, renderer.forced_seed = base, seed
-            try:
-                out = renderer(net, rays, want_weights=self._want_weights)
-            finally:
-                renderer.ray_index_base, renderer.forced_seed = 0, None
-            cols = []
-            for lv in lvls():
-                cols += [out[lv].rgb, out[lv].depth] + ([out[lv].weights] if self._want_weights else [])
-            return cols
-        self.sharded = ShardedRenderer(render_shard, group=group)
+    def _levels(self):
+        r = self.renderer
+        if self.simple_output:
+            return ("fine",) if r.using_fine else ("coarse",)
+        return ("coarse", "fine") if r.using_fine else ("coarse",)
 
     def _sample_counts(self):
         r = self.renderer
         return {"coarse": int(r.n_coarse), "fine": int(r.n_coarse) + int(r.n_fine)}
 
-    def forward(self, rays, want_weights=False):
-        if rays.shape[0] == 0:
-            return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
-        # per-sample weights (nested output only, nerf.py:33-41) travel in the same all_gather as rgb and depth
-        self._want_weights = bool(want_weights) and not self.simple_output
+    def _widths(self):
         widths = []
         for lv in self._levels():
             widths += [3, 1] + ([self._sample_counts()[lv]] if self._want_weights else [])
-        cols = self.sharded.gather(rays, widths)
+        return widths
+
+    def _keyed(self, base, seed, obj_stride):
+        r = self.renderer
+        r.ray_index_base, r.forced_seed, r.ray_index_obj_stride = base, seed, obj_stride
+
+    def _render_shard(self, rays, base, seed, obj_stride=0):
+        """Fallback route (a renderer without packed outputs): returns the per-level tensors, the caller packs them."""
+        self._keyed(base, seed, obj_stride)
+        try:
+            out = self.renderer(self.net, rays, want_weights=self._want_weights)
+        finally:
+            self._keyed(0, None, 0)
+        cols = []
+        for lv in self._levels():
+            cols += [out[lv].rgb, out[lv].depth] + ([out[lv].weights] if self._want_weights else [])
+        return cols
+
+    def _render_into(self, rays, base, seed, obj_stride, out):
+        """rays (SB, n, 8) -> out (SB, n, sum(widths)), this rank's slice of the gather buffer, written by the render launch
+        itself.  Returns False when this renderer / model pair has no packed route (the caller then uses _render_shard)."""
+        from ..model.models import PixelNeRFNet
+        if not (isinstance(self.net, PixelNeRFNet) and hasattr(self.renderer, "_forward_fused") and rays.is_cuda):
+            return False
+        self._keyed(base, seed, obj_stride)
+        try:
+            self.renderer.forward_packed(self.net, rays, out, self._levels(), self._want_weights)
+        finally:
+            self._keyed(0, None, 0)
+        return True
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
+        if getattr(self.net, "wants_grad", None) is not None and self.net.wants_grad(rays):
+            return self.local(rays, want_weights)          # training: rank-local, see the class docstring
+        # per-sample weights (nested output only, nerf.py:33-41) travel in the same all_gather as rgb and depth
+        self._want_weights = bool(want_weights) and not self.simple_output
+        cols = self.sharded.gather(rays, self._widths())
         if self.simple_output:
             return cols[0], cols[1]
         per = 3 if self._want_weights else 2
@@ -101,6 +133,7 @@ class NeRFRenderer(torch.nn.Module):
         # noise_c (N,Kc), u (N,Kf-Kfd), r (N,Kf-Kfd), g (N,Kfd) to inject explicit draws (parity tests).
         self.fixed_noise = None
         self.ray_index_base = 0      # global index of rays[0] when a frame is sharded over ranks
+        self.ray_index_obj_stride = 0   # rays per object of the UNSHARDED batch when a shard holds a range of several objects' rays
         self.last_seed = None
         self.forced_seed = None      # explicit kernel seed (ShardedRenderer: same seed on every rank)
         self._ws = None
@@ -198,9 +231,21 @@ class NeRFRenderer(torch.nn.Module):
             raise NotImplementedError("sigma noise (nerf.py:225-226) exists on the differentiable path only")
         return self._forward_generic(model, rays, want_weights)
 
-    def _forward_fused(self, net, rays, want_weights, camera=None):
+    def forward_packed(self, net, rays, out, levels, want_weights):
+        """forward() of a PixelNeRFNet with the outputs of `levels` written as ONE record per ray into out (SB, B, tot):
+        per level [rgb(3), depth(1), weights(K) if want_weights] — by the render launch itself (pnr_outputs strides).
+        What parallel.ShardedRenderer hands its rank's slice of the all_gather buffer to."""
+        if self.sched is not None and self.last_sched.item() > 0:
+            self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+            self.n_fine = self.sched[2][self.last_sched.item() - 1]
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[:2] == rays.shape[:2]):
+            raise ValueError("packed output must be a contiguous float32 (SB, B, tot) tensor on the rays' device")
+        return self._forward_fused(net, rays, want_weights, packed=(out, tuple(levels)))
+
+    def _forward_fused(self, net, rays, want_weights, camera=None, packed=None):
         """rays (SB, B, 8) through pnr_render; or, with rays=None, the pixels of `camera` = (c2w 16 floats, W, H, fx, fy,
-        cx, cy, z_near, z_far, pix0, n) through pnr_render_camera (rays generated inside the render launch)."""
+        cx, cy, z_near, z_far, pix0, n) through pnr_render_camera (rays generated inside the render launch).
+        packed = (out (SB, B, tot), levels): see forward_packed."""
         if camera is None:
             SB, B, _ = rays.shape
             dev = N.same_device(rays, net.poses)
@@ -222,18 +267,42 @@ class NeRFRenderer(torch.nn.Module):
         if v.n_objs != SB:
             raise ValueError(f"rays has {SB} objects but encode() saw {v.n_objs}")
         o = N.pnr_outputs()
-        res = AttrDict(coarse=AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev)))
-        o.coarse_rgb, o.coarse_depth = N.ptr(res.coarse.rgb), N.ptr(res.coarse.depth)
-        if want_weights:
-            res.coarse.weights = torch.empty(SB, B, Kc, device=dev)
-            o.coarse_weights = N.ptr(res.coarse.weights)
-        if Kf > 0:
-            res.fine = AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev))
-            o.fine_rgb, o.fine_depth = N.ptr(res.fine.rgb), N.ptr(res.fine.depth)
+        if packed is not None:
+            # one record per ray in the caller's buffer: the members of pnr_outputs point INTO it, with the record length as
+            # their row stride; levels that are not asked for stay NULL (the library keeps them in its workspace)
+            buf, levels = packed
+            tot, base, off = buf.shape[-1], buf.data_ptr(), 0
+            res = AttrDict()
+            for lv in levels:
+                if lv == "fine" and Kf == 0:
+                    raise ValueError("packed level 'fine' but the renderer has no fine pass")
+                K = Kc if lv == "coarse" else Kc + Kf
+                res[lv] = AttrDict(rgb=buf[..., off:off + 3], depth=buf[..., off + 3])
+                setattr(o, lv + "_rgb", base + 4 * off)
+                setattr(o, lv + "_depth", base + 4 * (off + 3))
+                off += 4
+                if want_weights:
+                    res[lv].weights = buf[..., off:off + K]
+                    setattr(o, lv + "_weights", base + 4 * off)
+                    off += K
+            if off != tot:
+                raise ValueError(f"packed record of {tot} floats, the levels {levels} need {off}")
+            o.rgb_stride = o.depth_stride = o.coarse_weights_stride = o.fine_weights_stride = tot
+            if Kf > 0 and "fine" not in levels:         # pnr_render needs somewhere to put the fine pixels
+                raise ValueError("a renderer with a fine pass packs its fine level (simple_output picks it)")
+        else:
+            res = AttrDict(coarse=AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev)))
+            o.coarse_rgb, o.coarse_depth = N.ptr(res.coarse.rgb), N.ptr(res.coarse.depth)
             if want_weights:
-                res.fine.weights = torch.empty(SB, B, Kc + Kf, device=dev)
-                o.fine_weights = N.ptr(res.fine.weights)
-        if getattr(self, "keep_samples", False):
+                res.coarse.weights = torch.empty(SB, B, Kc, device=dev)
+                o.coarse_weights = N.ptr(res.coarse.weights)
+            if Kf > 0:
+                res.fine = AttrDict(rgb=torch.empty(SB, B, 3, device=dev), depth=torch.empty(SB, B, device=dev))
+                o.fine_rgb, o.fine_depth = N.ptr(res.fine.rgb), N.ptr(res.fine.depth)
+                if want_weights:
+                    res.fine.weights = torch.empty(SB, B, Kc + Kf, device=dev)
+                    o.fine_weights = N.ptr(res.fine.weights)
+        if getattr(self, "keep_samples", False) and packed is None:
             res.coarse.z = torch.empty(SB, B, Kc, device=dev)
             o.z_coarse = N.ptr(res.coarse.z)
             if Kf > 0:
@@ -242,6 +311,7 @@ class NeRFRenderer(torch.nn.Module):
         if getattr(self, "point_events", None) is not None:      # (begin, end) native event handles, see bench.py
             o.ev_point_begin, o.ev_point_end = self.point_events
         nz, k4 = self._noise_ptrs(dev)
+        nz.ray_index_obj_stride = int(self.ray_index_obj_stride)
         nbytes = N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mc), C.byref(v), n)
         if mf is not None:      # the point workspace serves both passes: size it for the larger MLP
             nbytes = max(nbytes, N.lib.pnr_workspace_bytes(C.byref(prm), C.byref(mf), C.byref(v), n))
@@ -259,6 +329,8 @@ class NeRFRenderer(torch.nn.Module):
         return res
 
     def _forward_generic(self, model, rays, want_weights):
+        if self.ray_index_obj_stride:
+            raise NotImplementedError("a shard of several objects' rays is rendered by the PixelNeRFNet path only")
         SB = rays.shape[0]
         r = N.f32c(rays).reshape(-1, 8)
         z_coarse = self.sample_coarse(r)

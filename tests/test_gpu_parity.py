@@ -212,7 +212,8 @@ def _psnr(a, b):
 # weight streams it spreads 41.9 .. 72 dB in bf16 and 54 .. 85 dB in fp16 (tools/dev/e2e_fine_floor.py), the projected
 # and the general stream trading places by +-3 dB from seed to seed.  The precision statement for the fine pass is the
 # one at INJECTED fp32 sample positions (the bound above, also checked against the reference's own fine pass in
-# test_mfma_matches_reference).  End to end:
+# test_mfma_matches_reference).  End to end (a statistic of a discontinuous map: one flipped bin in one ray moves a
+# 150-ray PSNR by several dB, so the floors are meant for samples of >= ~1000 rays; the 16-ray fixtures clear them too):
 #   fp16: >= 50 dB — SURVEY §8(c)'s adopted bound holds end to end as well (measured minimum 54 dB);
 #   bf16: >= 40 dB — BELOW the §8(c) bound, bf16 only: a reported sanity floor under the measured spread (41.9 dB minimum),
 #         not a precision claim; bf16 is the dtype BASELINE.json names for cfg 2, fp16 is what precision="auto" selects.
@@ -905,7 +906,7 @@ def test_fused_kernel_shape_space(n_blocks, combine_layer, NS, lat, proj, prec):
                          spec["white_bkgd"], spec["lindisp"], noise, use_code_viewdirs=spec["use_code_viewdirs"],
                          n_blocks=n_blocks, combine_layer=combine_layer, combine_type=spec["combine_type"])
     rays = torch.from_numpy(rays_np).cuda()
-    outs = {}
+    nets, outs = {}, {}
     for p in ("fp32", prec):
         net = build_net(spec, poses, "cuda", p)
         net.project_latent = proj
@@ -913,6 +914,7 @@ def test_fused_kernel_shape_space(n_blocks, combine_layer, NS, lat, proj, prec):
         rend = build_renderer(spec)
         rend.fixed_noise = {k: v.cuda() for k, v in noise.items()}
         outs[p] = rend(net, rays, want_weights=True)
+        nets[p] = (net, rend)
     # the fp32 HIP path on this shape is pinned to the oracle like the fixtures pin it on the shipped shape
     for lvl in ("coarse", "fine"):
         assert maxdiff(outs["fp32"][lvl].rgb.cpu(), ref[lvl]["rgb"]) <= 1e-4, lvl
@@ -920,8 +922,27 @@ def test_fused_kernel_shape_space(n_blocks, combine_layer, NS, lat, proj, prec):
         # summation-order difference of the last layer at a few 1e-4 (measured 1.4e-4); a flipped bin would show as ~1e-1
         assert maxdiff(outs["fp32"][lvl].weights.cpu(), ref[lvl]["weights"]) <= 4e-4, lvl
     assert _psnr(outs[prec].coarse.rgb.cpu(), ref["coarse"]["rgb"]) >= FLOOR_DB[prec]
-    assert _psnr(outs[prec].fine.rgb.cpu(), ref["fine"]["rgb"]) >= FINE_E2E_FLOOR_DB[prec]
     assert not torch.isnan(outs[prec].fine.rgb).any()
+    # the fine pass against the (now pinned) fp32 path on 1500 rays with in-kernel noise: the precision bound at the fp32
+    # path's sample positions, the end-to-end floor on a sample large enough that ONE flipped bin does not decide it
+    # (on the 150 rays above a single flip moved fp16 to 49.6 dB on one shape and bf16 to 39.97 dB on another)
+    spec2 = dict(spec); spec2.update(N=1500)
+    rays2 = torch.from_numpy(gu.make_inputs(spec2)[0]).cuda()
+    K = spec["Kc"] + spec["Kf"]
+    o2, inj = {}, {}
+    for p in ("fp32", prec):
+        net, rend = nets[p]
+        rend.fixed_noise, rend.forced_seed, rend.keep_samples = None, 11, True
+        o2[p] = rend(net, rays2)
+        z32 = o2["fp32"].fine.z
+        xyz = (rays2[:, :, None, :3] + z32[..., None] * rays2[:, :, None, 3:6]).reshape(1, -1, 3).contiguous()
+        vd = rays2[:, :, None, 3:6].expand(-1, -1, K, -1).reshape(1, -1, 3).contiguous()
+        pts = net(xyz, coarse=False, viewdirs=vd).reshape(-1, K, 4).contiguous()
+        inj[p] = rend._composite_native(rays2.reshape(-1, 8), z32.reshape(-1, K).contiguous(), pts)[1].cpu()
+    assert _psnr(inj["fp32"], o2["fp32"].fine.rgb.cpu().reshape(-1, 3)) >= 90.0
+    assert _psnr(o2[prec].coarse.rgb.cpu(), o2["fp32"].coarse.rgb.cpu()) >= FLOOR_DB[prec]
+    assert _psnr(inj[prec], inj["fp32"]) >= FLOOR_DB[prec], "fine pass at the fp32 sample positions"
+    assert _psnr(o2[prec].fine.rgb.cpu(), o2["fp32"].fine.rgb.cpu()) >= FINE_E2E_FLOOR_DB[prec], "fine, end to end"
 
 
 @pytest.mark.parametrize("n_blocks,combine_layer,NS,lat", [

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.PROTOTYPES), declared ^ set(N.PROTOTYPES)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.pnr_version() == 100
+    assert N.lib.pnr_version() == 101
     assert N.lib.pnr_error_string(-4).decode() == "workspace too small"
 
 

@@ -207,3 +207,78 @@ def test_bind_parallel_without_process_group_warns_and_renders_on_one_device():
     assert torch.equal(rgb, ref[0] * 0.5) and torch.equal(depth, ref[1] * 0.5)
     rgb0, depth0 = render_par(torch.zeros(0, 8))            # zero-ray early-out (nerf.py:23-27)
     assert rgb0.shape == (0, 3) and depth0.shape == (0,)
+
+
+# ----------------------------------------------------------------------------- training under the same binding (train/train.py:171,331)
+class _TinyNet(torch.nn.Module):
+    """Stand-in with PixelNeRFNet's training switch (wants_grad) and a differentiable CPU body."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([[0.3, -0.2, 0.5], [0.1, 0.4, -0.6], [0.7, 0.2, 0.1]]))
+
+    def wants_grad(self, *inputs):
+        return self.training and torch.is_grad_enabled()
+
+
+def _diff_renderer_cls():
+    from pixel_nerf_multiscale_amd import NeRFRenderer
+    from pixel_nerf_multiscale_amd.util import AttrDict
+
+    class DiffRenderer(NeRFRenderer):
+        def forward(self, model, rays, want_weights=False):
+            rgb = torch.tanh(rays[..., 3:6] @ model.w)
+            return AttrDict(coarse=AttrDict(rgb=rgb, depth=rays[..., 6] * model.w.sum()))
+    return DiffRenderer
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pixel_nerf_multiscale_amd.parallel import allreduce_gradients
+        g = torch.Generator().manual_seed(3)
+        batch = torch.rand(1, 8 * world, 8, generator=g)               # the concatenated batch; rank r trains on its slice
+        net = _TinyNet()
+        rend = _diff_renderer_cls()(n_coarse=4, n_fine=0)
+        render_par = rend.bind_parallel(net, list(range(world))).eval()  # train.py:171; .eval() reaches the net as well ...
+        net.train()                                                      # ... and the trainer switches it back per step
+        mine = batch[:, 8 * rank:8 * (rank + 1)]
+        out = render_par(mine, want_weights=True)                        # train.py:331: rank-local, differentiable
+        assert out["coarse"]["rgb"].requires_grad and tuple(out["coarse"]["rgb"].shape) == (1, 8, 3)
+        loss = out["coarse"]["rgb"].square().mean() + out["coarse"]["depth"].mean()
+        loss.backward()
+        allreduce_gradients(list(net.parameters()))                      # the step hook
+        # eval-mode calls through the SAME binding are sharded again
+        net.eval()
+        with torch.no_grad():
+            full = render_par(batch)
+        q.put((rank, net.w.grad.numpy().copy(), full["coarse"]["rgb"].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_training_call_is_rank_local_and_averaged_gradients_equal_the_whole_batch(world):
+    """Two (three) ranks, each back-propagating its own slice through the binding bind_parallel returns, then
+    allreduce_gradients: the result equals the single-process gradient of the concatenated batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    batch = torch.rand(1, 8 * world, 8, generator=g)
+    net = _TinyNet()
+    rend = _diff_renderer_cls()(n_coarse=4, n_fine=0)
+    out = rend(net, batch)
+    (out.coarse.rgb.square().mean() + out.coarse.depth.mean()).backward()
+    for rank, grad, full in res:
+        assert torch.allclose(torch.from_numpy(grad), net.w.grad, rtol=1e-5, atol=1e-7), rank
+        assert torch.allclose(torch.from_numpy(full), out.coarse.rgb.detach(), rtol=0, atol=0), rank

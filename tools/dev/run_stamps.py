@@ -8,6 +8,8 @@ import bench
 from pixel_nerf_multiscale_amd import _native as N
 wl = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
 spec, net, rend, rays = bench.build(wl, "bf16", torch.device("cuda"))
+if len(sys.argv) > 2:          # fewer rays: fewer workgroups active at once (how much of a section is contention between CUs?)
+    rays = rays[:, :int(sys.argv[2])].contiguous()
 fn = N.lib._cdll.pnr_debug_stamps
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 16)()
@@ -19,9 +21,11 @@ import time
 torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(5): rend(net, rays)
 torch.cuda.synchronize(); print("ms/frame (stamped build)", (time.perf_counter()-t0)/5*1e3)
-names = ["tile total", "prologue(geom+posenc)", "lin_in+gather/taps", "lin_z groups (gather + x-stages)", "-", "-", "resblock asm (lin_z tail + bias + 16 chunks)", "bias + lin_out + store"]
+names = ["tile total", "prologue(geom+posenc) [+ drain of the park stores at the LIN_IN entry]", "gather / taps behind LIN_IN", "lin_z tail of the block loop (tap image / last gather)",
+         "park statement (issue only)", "reduce statement", "resblock asm (lin_z prefix + bias + 16 chunks)", "bias + lin_out + store",
+         "LIN_IN statement", "compositing of the previous tile's rays", "gather / restore of a lin_z group", "x_stages(8) statement of a lin_z group"]
 tot = buf[0]
-n_tiles = rays.shape[1] * spec["Kc"] // 128
+n_tiles = rays.shape[1] * (spec["Kc"] + (spec["Kc"] + spec["Kf"] if spec["Kf"] else 0)) // 128      # both passes of a coarse+fine render
 for i, n in enumerate(names):
     if n != "-":
         print(f"{n:48s} {buf[i]/tot*100:6.2f}%   cycles/wave/tile = {buf[i]/ (3*4*n_tiles):10.0f}")

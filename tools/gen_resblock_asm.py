@@ -52,9 +52,12 @@ s20-s31, s33-s43 (s32 is the ABI stack pointer: left alone).
 import os
 import re
 
-# timing experiments only (results are garbage): nobarrier, nodma, nowait, nosnap, dma1, dmaearly, dmaplain, dmaquarter;
+# timing experiments only (results are garbage): nobarrier, nodma, nowait, nosnap, dma1, dmaearly, dmaplain, dmaquarter, nodsread,
+# nolgkm, noadvance; placement: align4; cache policy of the weight stream (results stay exact): nt0 .. nt3;
 # hazard experiments of round 2 (kept for the record, all explained by rule R1): fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA
 DIAG = os.environ.get("PNR_ASM_DIAG", "")
+# pieces q >= NT_FROM of every stage carry the non-temporal hint (nt0 = all .. nt3 = a quarter of the stream; default: none)
+NT_FROM = next((int(m.group(1)) for m in [re.search(r"\bnt([0-3])\b", DIAG)] if m), 4)
 
 
 def A(i):
@@ -95,6 +98,8 @@ class Emit:
         self.L.append(line)
 
     def ds_read(self, tag, text):
+        if "nodsread" in DIAG and tag.startswith("A"):      # timing only: no weight-fragment reads
+            return
         self.L.append(text)
         self.reads.append(tag)
         assert len(self.reads) <= 15, ("more than 15 LDS reads in flight", self.reads)
@@ -103,7 +108,8 @@ class Emit:
         idx = max([i for i, t in enumerate(self.reads) if t in tags], default=-1)
         if idx < 0:
             return
-        self.e(f"s_waitcnt lgkmcnt({len(self.reads) - 1 - idx})")
+        if "nolgkm" not in DIAG:                            # timing only: no counted LDS waits
+            self.e(f"s_waitcnt lgkmcnt({len(self.reads) - 1 - idx})")
         self.reads = self.reads[idx + 1:]
 
     def drain(self):
@@ -143,6 +149,8 @@ class Emit:
 
     def loader_advance(self):
         e = self.e
+        if "noadvance" in DIAG:                             # timing only: the loader re-reads one stage
+            return
         e("s_add_u32 s21, s21, 1")
         e("s_add_u32 s24, s24, 0x4000")
         e("s_addc_u32 s25, s25, 0")
@@ -190,7 +198,7 @@ class Emit:
                     e(f"s_mov_b32 m0, {m0_sreg}")
                     e("s_nop 0")
                 if "dma1" not in DIAG or q == 0:
-                    e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
+                    e("global_load_lds_dwordx4 v15, s[24:25]" + (f" offset:{q * 1024}" if q else "") + (" nt" if q >= NT_FROM else ""))
                 if q == 3:
                     self.loader_advance()
             base = rd_cur if f < 8 else rd_nxt
@@ -214,6 +222,8 @@ def entry_guard(e):
 def setup_cursor(E, cfg, stream):
     e = E.e
     entry_guard(e)
+    if "align4" in DIAG:                                     # placement experiment: shift the statement's text by 4 bytes
+        e("s_nop 0")
     e("s_nop 15")
     e("s_nop 15")                                            # accumulator writes of the caller's last MFMAs retired
     e("s_mov_b32 s39, m0")                                   # hipcc may keep a value in M0 across the statement
