@@ -742,42 +742,60 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
     }
 }
 
-// Latent gradient for ONE small map (C*T floats fit in LDS): a block owns a run of points of one (object, view), sums
-// their tap contributions in LDS ([texel][channel]: lanes = channels, conflict-free ds_add_f32) and flushes each entry
-// with a single global atomic — ~100x fewer global atomics than the per-point scatter of k_features_bwd, which on an
-// 8x8 map serialises on 64 texels.  dzx rows are view-major (row = v*P + g).
+// Latent gradient for ONE small map (C*T floats fit in LDS), bit-reproducible: a block owns a run of points of one
+// (object, view); thread t owns channels t, t + 256, .. and walks the run's points IN ORDER, adding their four tap
+// contributions into its own entries of an LDS map ([texel][channel]) — no entry is ever touched by two threads, so there
+// is no atomic and no race inside the block.  The block's partial map goes to its own slice of the backward workspace and
+// k_latent_reduce sums the slices in block order into d_latent (+=).  Replaces round 2's LDS float atomics + global
+// atomics (sum order = arrival order).  dzx rows are view-major (row = v*P + g).
+static constexpr int LATG_PPB = 256;                      // points per block (the tap table: 8 KiB of LDS)
 static __global__ void __launch_bounds__(256) k_latent_grad_lds(
     pnr_views vw, PointSrc src, int64_t P, int64_t pts_per_obj, int L, const float* __restrict__ dzx, int ldz,
-    float* __restrict__ d_lat, int pts_per_block) {
-    extern __shared__ float acc[];                         // [T][C]
+    float* __restrict__ part /* (blocks_x, views, T*C) */) {
+    extern __shared__ float acc[];                         // [T][C], then the tap table
     const int C = vw.lat_c[0], W = vw.lat_w[0], H = vw.lat_h[0], T = W * H;
+    int* tap_off = (int*)(acc + (size_t)T * C);            // [LATG_PPB][4]
+    float* tap_w = (float*)(tap_off + LATG_PPB * 4);       // [LATG_PPB][4]
     const int view = blockIdx.y, obj = view / vw.n_views, v = view % vw.n_views;
-    const int64_t g0 = (int64_t)obj * pts_per_obj + (int64_t)blockIdx.x * pts_per_block;
-    const int64_t g1 = min((int64_t)(obj + 1) * pts_per_obj, g0 + pts_per_block);
+    const int64_t g0 = (int64_t)obj * pts_per_obj + (int64_t)blockIdx.x * LATG_PPB;
+    const int64_t g1 = min((int64_t)(obj + 1) * pts_per_obj, g0 + LATG_PPB);
+    const int n = (int)(g1 - g0);
     for (int i = threadIdx.x; i < T * C; i += 256) acc[i] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    Cam cam = load_cam(vw, view);
-    for (int64_t g = g0 + wv; g < g1; g += 4) {            // one wave per point
+    if ((int)threadIdx.x < n) {                            // one thread per point: its four taps
         float p[3], d[3], xr[3], u, w;
-        fetch_point(src, g, p, d);
+        const Cam cam = load_cam(vw, view);
+        fetch_point(src, g0 + threadIdx.x, p, d);
         rot3(cam.R, p, xr);
         project(cam, xr, u, w);
-        Taps t = bilinear_taps(u, w, W, H);
-        const float* drow = dzx + ((size_t)v * P + g) * ldz;
-        for (int ch = lane; ch < C; ch += 64) {
-            float gz = drow[ch];
+        const Taps t = bilinear_taps(u, w, W, H);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (t.w[i] != 0.f) atomicAdd(&acc[t.off[i] * C + ch], gz * t.w[i]);
+        for (int i = 0; i < 4; ++i) { tap_off[threadIdx.x * 4 + i] = t.off[i]; tap_w[threadIdx.x * 4 + i] = t.w[i]; }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {        // the owner of channel ch, points in order
+        const float* dcol = dzx + ((size_t)v * P + g0) * ldz + ch;
+        for (int q = 0; q < n; ++q) {
+            const float gz = dcol[(size_t)q * ldz];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wgt = tap_w[q * 4 + i];
+                if (wgt != 0.f) acc[tap_off[q * 4 + i] * C + ch] += gz * wgt;
+            }
         }
     }
     __syncthreads();
-    float* out = d_lat + (size_t)view * C * T;             // (view, C, H, W)
-    for (int i = threadIdx.x; i < T * C; i += 256) {
-        float a = acc[i];
-        if (a != 0.f) atomicAdd(out + (size_t)(i % C) * T + i / C, a);
-    }
+    float* out = part + ((size_t)blockIdx.x * gridDim.y + view) * (size_t)T * C;
+    for (int i = threadIdx.x; i < T * C; i += 256) out[i] = acc[i];
+}
+
+// d_lat (view, C, H, W) += sum over the blocks' partial maps ([texel][channel]) in block order
+static __global__ void k_latent_reduce(const float* __restrict__ part, int nbx, int views, int C, int T, float* __restrict__ d_lat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // over (view, texel, channel)
+    if (i >= (int64_t)views * T * C) return;
+    const int view = (int)(i / ((int64_t)T * C)), r = (int)(i % ((int64_t)T * C));
+    float a = 0.f;
+    for (int b = 0; b < nbx; ++b) a += part[((size_t)b * views + view) * (size_t)T * C + r];
+    d_lat[(size_t)view * C * T + (size_t)(r % C) * T + r / C] += a;
 }
 
 // ------------------------------------------------------------------ composite backward (nerf.py:178-182,223-249)
@@ -942,9 +960,20 @@ static uint64_t det_ws_floats(const pnr_mlp* mlp) {
     return (uint64_t)DET_MAX_SPLITS * (wmax + H);
 }
 
+// one small single-level map: the latent gradient runs on per-block partial maps (k_latent_grad_lds); bytes of the slices
+static bool latent_grad_in_lds(const pnr_views* vw) {
+    return vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024;
+}
+static uint64_t latent_part_bytes(const pnr_views* vw, int64_t P) {
+    if (!latent_grad_in_lds(vw) || vw->n_objs < 1) return 0;
+    const uint64_t nbx = ((uint64_t)(P / vw->n_objs) + LATG_PPB - 1) / LATG_PPB;
+    return nbx * vw->n_objs * vw->n_views * (uint64_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4;
+}
+
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
     const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;
-    return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + a256(det_ws_floats(mlp) * 4) + 256;
+    return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + a256(det_ws_floats(mlp) * 4) +
+           a256(latent_part_bytes(vw, P)) + 256;
 }
 
 static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
@@ -1156,7 +1185,8 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* dh = (float*)wp;                wp += a256((uint64_t)MV * H * 4);
     float* dzx = (float*)wp;               wp += a256((uint64_t)MV * E * 4);
     float* do4 = (float*)wp;               wp += a256((uint64_t)P * 16);
-    const DetWs dws{(float*)wp, det_ws_floats(mlp)};
+    const DetWs dws{(float*)wp, det_ws_floats(mlp)};  wp += a256(det_ws_floats(mlp) * 4);
+    float* lat_part = (float*)wp;
     const bool want_p = d_xyz || d_z;
     bool want_lat = false;
     LatGrad lg{};
@@ -1195,14 +1225,16 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     if ((want_p || want_lat) && L > 0 && !dz_started) PNR_HIP_CHECK(hipMemsetAsync(dzx, 0, (size_t)MV * E * 4, s));
     if (want_p)
         PNR_TRY((gemm<false, true>(dx, H, mlp->lin_in_w, Din, nullptr, nullptr, 0, nullptr, 0, dzx + L, E, MV, Din, H, s, half)));
-    // small single-level map: latent gradient through LDS-privatised sums (k_latent_grad_lds)
-    if (want_lat && L > 0 && vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024) {
-        const int ppb = 256;          // 128 blocks for a 4 x 8192-point step: parallel enough, 16K flush atomics per block
-        const size_t lds = (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4;
-        dim3 grid((unsigned)((pts_per_obj + ppb - 1) / ppb), vw->n_objs * vw->n_views);
-        if (lds > 48 * 1024)
-            PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_latent_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_latent_grad_lds, grid, dim3(256), lds, s, *vw, src, P, pts_per_obj, L, dzx, E, lg.p[0], ppb);
+    // small single-level map: latent gradient on per-block partial maps + an ordered reduction (bit-reproducible)
+    if (want_lat && L > 0 && latent_grad_in_lds(vw)) {
+        const int T = vw->lat_h[0] * vw->lat_w[0], C = vw->lat_c[0], views = vw->n_objs * vw->n_views;
+        const size_t lds = (size_t)C * T * 4 + (size_t)LATG_PPB * 4 * 8;
+        const int nbx = (int)((pts_per_obj + LATG_PPB - 1) / LATG_PPB);
+        PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_latent_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_latent_grad_lds, dim3(nbx, views), dim3(256), lds, s, *vw, src, P, pts_per_obj, L, dzx, E, lat_part);
+        PNR_LAUNCH_CHECK();
+        const int64_t tot = (int64_t)views * T * C;
+        hipLaunchKernelGGL(k_latent_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, lat_part, nbx, views, C, T, lg.p[0]);
         PNR_LAUNCH_CHECK();
         lg.p[0] = nullptr;
         want_lat = false;

@@ -10,6 +10,8 @@ and writes what the reference's eval scripts do.  Pure host-side parsing and ari
                               (data_range=1, multichannel): restated from the published definitions — skimage is not
                               installed here and the reference's own numbers need its dataset, so SSIM is "parity unpinned".
 * checkpoints                 three mutually incompatible schemas in the reference tree
+* evaluate()                  reference eval/eval.py:186-362           the per-object loop that composes the above with
+                              encode -> render -> clamp -> metrics -> finish.txt (resume), on this package's renderer
 """
 import os
 
@@ -106,3 +108,159 @@ def load_checkpoint(net, path, device=None, strict=False):
     ck = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ck.items()}   # DataParallel prefix
     res = net.load_state_dict(ck, strict=strict)
     return list(res.missing_keys), list(res.unexpected_keys)
+
+
+def write_png(path, rgb_u8):
+    """8-bit RGB PNG from an (H, W, 3) uint8 array with the standard library only (the reference writes through imageio,
+    eval/eval.py:301; the pixel values are what matters for calc_metrics.py, not the encoder)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    raw = b"".join(b"\x00" + a[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None, eval_view_list=None,
+             include_src=False, scale=1.0, multicat=False, gpu_id=None, ray_batch_size=50000, no_compare_gt=False,
+             write_compare=False, write_images=True, max_objects=50, z_near=None, z_far=None,
+             verbose=True):
+    """The per-object evaluation loop of the reference (eval/eval.py:186-362) on this package's renderer.
+
+    dataset: a sequence of per-object dicts as the reference's datasets yield them (unbatched): "path", "images"
+    (NV, 3, H, W) in [-1, 1], "poses" (NV, 4, 4) camera-to-world, "focal" (float | tensor), optional "c"; z_near / z_far
+    from the arguments or the dataset's attributes (eval.py:153-154).  net / renderer as the driver sets them up
+    (eval.py:136-151: caller-side overrides of n_coarse / n_fine / mlp_fine stay with the caller).
+
+    Per object (eval.py:186-362): resume — objects already in <output_dir>/finish.txt are skipped (:113-133, :203-205);
+    source views from `source` ("0 1 2") or the look-up table file / dict `viewlist` keyed "<cat>/<obj>" (:156-165,
+    :224-231); target views = eval_view_list (file / indices) minus the source views unless include_src (:170-178,
+    :246-248); net.encode on the source images (:271-276); every target view rendered — as ONE call per view with the rays
+    generated inside the render launch (NeRFRenderer.render_image) on one device, or through renderer.bind_parallel(net,
+    gpu_id, simple_output=True) in chunks of ray_batch_size when a process group is up (:151, :267, :279-284) — with the
+    frames brought to the host asynchronously (frame_to_host_async) while the next view renders; clamp to [0, 1] and
+    reshape (:286-293); PNGs "<obj>/<view:06>.png" quantised by truncation (:294-301); PSNR / SSIM per view against
+    images * 0.5 + 0.5, averaged per object (:318-347); running means and a "<obj> <psnr> <ssim> 1" line appended to
+    finish.txt (:348-362).  Returns (mean_psnr, mean_ssim, n_objects_counted) over everything in finish.txt.
+
+    Deliberate differences: the rays of all target views are not concatenated and re-split (:250-267) — a view is the unit;
+    the random jitter is keyed by (seed, ray) so chunking does not change results; SSIM is this module's restatement
+    (skimage is not importable here: parity unpinned); depth EXR / colour-mapped depth outputs (:303-316) are not written."""
+    import torch.distributed as dist
+    from . import util
+    dev = net.poses.device
+    z_near = float(getattr(dataset, "z_near", None) if z_near is None else z_near)
+    z_far = float(getattr(dataset, "z_far", None) if z_far is None else z_far)
+    has_output = bool(output_dir and str(output_dir).strip())
+    log = FinishLog(os.path.join(output_dir, "finish.txt")) if has_output else None
+    total_psnr, total_ssim, cnt = (log.total_psnr, log.total_ssim, log.cnt) if log else (0.0, 0.0, 0)
+    if log and log.cnt > 0 and verbose:
+        print("resume psnr", log.total_psnr / log.cnt, "ssim", log.total_ssim / log.cnt)
+
+    if isinstance(viewlist, str) and viewlist:
+        viewlist = read_source_view_lut(viewlist)
+    use_lut = bool(viewlist)
+    fixed_source = None if use_lut else torch.tensor(sorted(int(x) for x in str(source).split()), dtype=torch.long)
+    if isinstance(eval_view_list, str):
+        eval_view_list = read_eval_view_list(eval_view_list)
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    render_par = renderer.bind_parallel(net, gpu_id, simple_output=True).eval() if sharded else None
+    was_training = net.training
+    net.eval()
+    try:
+        with torch.no_grad():
+            for obj_idx in range(len(dataset)):
+                if max_objects is not None and obj_idx >= max_objects:      # eval.py:187 stops after 50 objects
+                    break
+                data = dataset[obj_idx]
+                dpath = data["path"]
+                obj_base, cat_name = os.path.basename(dpath), os.path.basename(os.path.dirname(dpath))
+                obj_name = cat_name + "_" + obj_base if multicat else obj_base
+                if verbose:
+                    print("OBJECT", obj_idx, "OF", len(dataset), dpath)
+                if log and obj_name in log.finished:
+                    if verbose:
+                        print("(skip)")
+                    continue
+                images = data["images"]                                       # (NV, 3, H, W)
+                NV, _, H, W = images.shape
+                if scale != 1.0:
+                    Ht, Wt = int(H * scale), int(W * scale)
+                    if abs(Ht / scale - H) > 1e-10 or abs(Wt / scale - W) > 1e-10:
+                        import warnings
+                        warnings.warn(f"Inexact scaling, please check {scale} times ({H}, {W}) is integral")
+                    H, W = Ht, Wt
+                src = viewlist[cat_name + "/" + obj_base] if use_lut else fixed_source
+                src_mask = torch.zeros(NV, dtype=torch.bool)
+                src_mask[src] = True
+                tgt_mask = torch.ones(NV, dtype=torch.bool)
+                if eval_view_list is not None:
+                    tgt_mask = torch.zeros(NV, dtype=torch.bool)
+                    tgt_mask[torch.as_tensor(eval_view_list, dtype=torch.long)] = True
+                if not include_src:
+                    tgt_mask = tgt_mask & ~src_mask
+                novel = tgt_mask.nonzero(as_tuple=False).reshape(-1)
+                focal = data["focal"]
+                focal = torch.tensor(focal, dtype=torch.float32) if isinstance(focal, float) else torch.as_tensor(focal).float()
+                c = data.get("c")
+                c = None if c is None else torch.as_tensor(c).float()
+                poses = torch.as_tensor(data["poses"]).float()
+                net.encode(images[src_mask].to(dev).unsqueeze(0), poses[src_mask].to(dev).unsqueeze(0), focal[None].to(dev),
+                           c=None if c is None else c.to(dev).unsqueeze(0))
+                frames, pending = [], None
+                for vi in novel.tolist():
+                    if render_par is None:
+                        rgb, depth = renderer.render_image(net, poses[vi], W, H, focal * scale, z_near, z_far,
+                                                           c=None if c is None else c * scale)
+                    else:
+                        rays = util.gen_rays_device(poses[vi], W, H, focal * scale, z_near, z_far,
+                                                    c=None if c is None else c * scale, device=dev)
+                        parts = [render_par(r[None]) for r in torch.split(rays, ray_batch_size, dim=0)]
+                        rgb = torch.cat([p[0][0] for p in parts], 0).reshape(H, W, 3)
+                        depth = torch.cat([p[1][0] for p in parts], 0).reshape(H, W)
+                    nxt = renderer.frame_to_host_async(rgb, depth)          # D2H overlaps the next view's render
+                    if pending is not None:
+                        pending[2].synchronize()
+                        frames.append(pending[0])
+                    pending = nxt
+                if pending is not None:
+                    pending[2].synchronize()
+                    frames.append(pending[0])
+                all_rgb = torch.clamp(torch.stack(frames), 0.0, 1.0).numpy() if frames else np.zeros((0, H, W, 3), np.float32)
+                n_gen = len(frames)
+                if has_output and write_images:
+                    obj_out = os.path.join(output_dir, obj_name)
+                    os.makedirs(obj_out, exist_ok=True)
+                    for i in range(n_gen):
+                        write_png(os.path.join(obj_out, "{:06}.png".format(int(novel[i]))), quantize_uint8(all_rgb[i]))
+                curr_psnr = curr_ssim = 0.0
+                if not no_compare_gt and n_gen:
+                    gt = (images * 0.5 + 0.5)[tgt_mask].permute(0, 2, 3, 1).contiguous().numpy()
+                    for i in range(n_gen):
+                        curr_ssim += ssim(all_rgb[i], gt[i], data_range=1)
+                        curr_psnr += psnr(all_rgb[i], gt[i], data_range=1)
+                        if has_output and write_compare:
+                            write_png(os.path.join(output_dir, obj_name, "{:06}_compare.png".format(int(novel[i]))),
+                                      quantize_uint8(np.hstack((all_rgb[i], gt[i]))))
+                    curr_psnr /= n_gen
+                    curr_ssim /= n_gen
+                total_psnr += curr_psnr
+                total_ssim += curr_ssim
+                cnt += 1
+                if verbose and not no_compare_gt:
+                    print("curr psnr", curr_psnr, "ssim", curr_ssim, "running psnr", total_psnr / cnt, "running ssim", total_ssim / cnt)
+                if log:
+                    log.append(obj_name, curr_psnr, curr_ssim, 1)
+    finally:
+        net.train(was_training)
+        if log:
+            log.close()
+    if verbose and cnt:
+        print("final psnr", total_psnr / cnt, "ssim", total_ssim / cnt)
+    return (total_psnr / cnt, total_ssim / cnt, cnt) if cnt else (0.0, 0.0, 0)

@@ -63,3 +63,31 @@ def test_checkpoint_schemas(tmp_path):
         missing, unexpected = evalio.load_checkpoint(dst, str(path))
         assert not missing and not unexpected, name
         assert float(dst.mlp_coarse.lin_out.bias.detach()[0]) == 0.25, name
+
+
+def test_write_png_round_trip(tmp_path):
+    """evalio.write_png: a standard 8-bit RGB PNG (decoded here with zlib by hand: signature, IHDR, filter-0 scanlines)."""
+    import struct
+    import zlib
+    import numpy as np
+    from pixel_nerf_multiscale_amd import evalio
+    rng = np.random.default_rng(0)
+    img = rng.random((13, 7, 3)).astype(np.float32)
+    u8 = evalio.quantize_uint8(img)
+    p = tmp_path / "a.png"
+    evalio.write_png(str(p), u8)
+    raw = p.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks.append((tag, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (w, h, depth, ctype) == (7, 13, 8, 2)
+    rows = zlib.decompress(chunks[1][1])
+    back = np.frombuffer(rows, np.uint8).reshape(13, 1 + 7 * 3)
+    assert (back[:, 0] == 0).all() and (back[:, 1:].reshape(13, 7, 3) == u8).all()
