@@ -53,9 +53,16 @@ __device__ __forceinline__ int64_t global_ray(const RayKey& k, int64_t r) {
     return k.base + r + (k.extra != 0 ? (r / k.rays_per_obj) * k.extra : 0);
 }
 
+// Uniform draw `idx` of (seed, ray, draw): word idx & 3 of the Philox block idx >> 2 — four consecutive draws share one
+// block, so a thread that produces four samples of a ray (k_sample_coarse) pays for one block, and every kernel that asks
+// for a single draw gets the same number.
+__device__ __forceinline__ u32x4 rng_block(uint64_t seed, int64_t ray, int draw, int blk) {
+    return philox4x32(seed, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), (uint32_t)draw, (uint32_t)blk);
+}
 __device__ __forceinline__ float rng_uniform(uint64_t seed, int64_t ray, int draw, int idx) {
-    u32x4 v = philox4x32(seed, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), (uint32_t)draw, (uint32_t)idx);
-    return u01(v.x);
+    const u32x4 v = rng_block(seed, ray, draw, idx >> 2);
+    const int w = idx & 3;
+    return u01(w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w);
 }
 __device__ __forceinline__ float rng_normal(uint64_t seed, int64_t ray, int draw, int idx) {
     u32x4 v = philox4x32(seed, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), (uint32_t)draw, (uint32_t)idx);

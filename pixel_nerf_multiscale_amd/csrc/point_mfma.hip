@@ -907,7 +907,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 view_pass();
                 const float4* slot = slot0 + (size_t)v * 4096;
                 const uint32_t lane16 = lane_id() * 16;
-                asm volatile(PNR_VIEWSPILL_ASM : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
+                if (DT == PNR_BF16) asm volatile(PNR_VIEWSPILL_ASM_BF16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
+                else asm volatile(PNR_VIEWSPILL_ASM_F16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
                 STAMP_ACC(4, st_t);
             }
             view_pass();
@@ -916,8 +917,12 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             asm volatile("" : "+s"(ns_q));                  // formed here, not kept from the kernel's entry in scratch
             const float inv = 1.0f / (float)ns_q;
             const uint32_t lane16 = lane_id() * 16;
-            asm volatile(PNR_VIEWREDUCE_ASM : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
-                         : PNR_RESBLOCK_CLOBBERS);
+            if (DT == PNR_BF16)
+                asm volatile(PNR_VIEWREDUCE_ASM_BF16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
+                             : PNR_RESBLOCK_CLOBBERS);
+            else
+                asm volatile(PNR_VIEWREDUCE_ASM_F16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
+                             : PNR_RESBLOCK_CLOBBERS);
             STAMP_ACC(5, st_t);
         } else {
             view_pass();

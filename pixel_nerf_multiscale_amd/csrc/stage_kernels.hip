@@ -6,17 +6,39 @@
 namespace pnr {
 
 // ------------------------------------------------------------------ sample_coarse  (nerf.py:98-118): z_from_t / linspace_k in pnr_common.h
+// One thread = four consecutive samples of a ray: one Philox block (rng_block), one 16-byte store where the row is
+// aligned — the stage is bound by its 4K B/ray of output once the generator is amortised.
 __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, int Kc, int lindisp,
                                 const float* __restrict__ noise, uint64_t seed, RayKey key,
                                 float* __restrict__ z_out) {
+    const int q_per_ray = (Kc + 3) >> 2;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rays * Kc) return;
-    int64_t ray = idx / Kc;
-    int k = (int)(idx % Kc);
-    float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
-    float u = noise ? noise[idx] : rng_uniform(seed, global_ray(key, ray), DRAW_COARSE, k);
-    float t = fmaf(u, 1.0f / (float)Kc, linspace_k(k, Kc));
-    z_out[idx] = z_from_t(t, near, far, lindisp);
+    if (idx >= n_rays * q_per_ray) return;
+    const int64_t ray = idx / q_per_ray;
+    const int k0 = (int)(idx % q_per_ray) * 4;
+    const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+    float u[4];
+    if (noise) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (k0 + j < Kc) ? noise[ray * Kc + k0 + j] : 0.f;
+    } else {
+        const u32x4 v = rng_block(seed, global_ray(key, ray), DRAW_COARSE, k0 >> 2);
+        u[0] = u01(v.x); u[1] = u01(v.y); u[2] = u01(v.z); u[3] = u01(v.w);
+    }
+    float z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t = fmaf(u[j], 1.0f / (float)Kc, linspace_k(k0 + j < Kc ? k0 + j : Kc - 1, Kc));
+        z[j] = z_from_t(t, near, far, lindisp);
+    }
+    float* o = z_out + ray * Kc + k0;
+    if ((Kc & 3) == 0 && (((uintptr_t)z_out) & 15) == 0) {
+        *(float4*)o = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < Kc) o[j] = z[j];
+    }
 }
 
 // ------------------------------------------------------------------ composite  (nerf.py:178-182,223-249): composite_ray in pnr_common.h
@@ -83,7 +105,7 @@ int32_t sample_coarse_launch(const float* rays, int64_t n_rays, int32_t n_coarse
     if (!rays || !z_out) return PNR_E_NULL;
     if (n_rays < 0 || n_coarse <= 0) return PNR_E_SHAPE;
     if (n_rays == 0) return PNR_OK;
-    int64_t tot = n_rays * n_coarse;
+    int64_t tot = n_rays * ((n_coarse + 3) / 4);
     hipLaunchKernelGGL(k_sample_coarse, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rays, n_rays, n_coarse, lindisp, noise_c, seed, key, z_out);
     PNR_LAUNCH_CHECK();

@@ -407,7 +407,10 @@ def test_mfma_vs_fp32_path_superbatch_and_views(NS, SB, cv, comb):
     the fixtures do not hold at d_hidden=512: several objects per call, 2/4 source views, coded viewdirs."""
     from hip_util import build_net, build_renderer
     import golden_util as gu
-    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=2000, use_code_viewdirs=cv, seed=70 + NS + SB, combine_type=comb)
+    # the reference's sample schedule (conf/default.conf:50-53: 64 coarse + 32 fine, 16 of them depth-guided): the end-to-end
+    # fine statistic is about bins flipping, and with a toy 16-bin schedule one flip moves a sample by 1/16 of the ray
+    spec = dict(gu.CASES["full_ns1"]); spec.update(NS=NS, SB=SB, N=2000, use_code_viewdirs=cv, seed=70 + NS + SB, combine_type=comb,
+                                                   Kc=64, Kf=32, Kfd=16)
     rays_np, poses = gu.make_inputs(spec)
     rays = torch.from_numpy(rays_np).cuda()
     outs, fine_fixed = {}, {}
@@ -926,12 +929,14 @@ def test_fused_kernel_shape_space(n_blocks, combine_layer, NS, lat, proj, prec):
     # the fine pass against the (now pinned) fp32 path on 1500 rays with in-kernel noise: the precision bound at the fp32
     # path's sample positions, the end-to-end floor on a sample large enough that ONE flipped bin does not decide it
     # (on the 150 rays above a single flip moved fp16 to 49.6 dB on one shape and bf16 to 39.97 dB on another)
+    # ... at the reference's sample schedule (64 + 32, conf/default.conf:50-53), where the statistic means something
     spec2 = dict(spec); spec2.update(N=1500)
     rays2 = torch.from_numpy(gu.make_inputs(spec2)[0]).cuda()
-    K = spec["Kc"] + spec["Kf"]
+    K = 64 + 32
     o2, inj = {}, {}
     for p in ("fp32", prec):
         net, rend = nets[p]
+        rend.n_coarse, rend.n_fine, rend.n_fine_depth = 64, 32, 16
         rend.fixed_noise, rend.forced_seed, rend.keep_samples = None, 11, True
         o2[p] = rend(net, rays2)
         z32 = o2["fp32"].fine.z

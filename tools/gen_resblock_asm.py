@@ -57,6 +57,9 @@ import re
 # hazard experiments of round 2 (kept for the record, all explained by rule R1): fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA
 DIAG = os.environ.get("PNR_ASM_DIAG", "")
 # pieces q >= NT_FROM of every stage carry the non-temporal hint (nt0 = all .. nt3 = a quarter of the stream; default: none)
+# cache policy of the park stores / reduce loads (experiments: parknt, reducent; results stay exact)
+PARK_POLICY = " nt" if "parknt" in DIAG else ""
+REDUCE_POLICY = " nt" if "reducent" in DIAG else ""
 NT_FROM = next((int(m.group(1)) for m in [re.search(r"\bnt([0-3])\b", DIAG)] if m), 4)
 
 
@@ -600,60 +603,75 @@ def gen_linout(dt):
     return E.L
 
 
-def gen_viewspill():
-    """Park this view's residual stream: the 256 accumulator registers -> workspace slot, float4 index (t*4+q)*64 + lane
-    (layout-agnostic: the reduce reads the same registers back).  Operands: %0-%15 x tiles (pinned), %16 slot base (s64),
-    %17 lane*16 (v).  Writes no VGPR (rule R1 does not apply; the audit checks that).  Hazard: MFMA write -> VMEM read of the
-    AGPR (entry s_nop)."""
-    L = []
-    e = L.append
+def gen_viewspill(dt):
+    """Park this view's residual stream in the kernel's 16-bit format (bf16 / fp16): the 256 accumulator registers -> 32 KiB of
+    the wave's workspace slot, dwordx4 index (2 t + q) * 64 + lane holding accumulators 16 t + 8 q .. + 7 of the lane as four
+    (even, odd) pairs (the reduce reads the same mapping back).  Half the bytes of an fp32 park: with every CU parking at the
+    same moment the stores queue on the fabric (13.4 k cycles per park with 256 workgroups against 4.7 k with 32,
+    profiles/r03_park_contention.txt), so bytes are time.  The rounding is the one every layer's input already takes (the
+    next reader of x is relu -> 16-bit for fc_0); fp16 saturates at +-65504 like the activations.
+    Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v).  Writes v68-71 / v96-223 (rule R1: entry guard)."""
+    E = Emit(dt)
+    e = E.e
+    entry_guard(e)
     e("s_nop 15")
-    e("s_nop 15")
+    e("s_nop 15")                                            # MFMA write -> accumulator read
     e("s_mov_b64 s[24:25], %16")
+    if dt == "f16":
+        e("s_mov_b32 s38, 0x7bff7bff")
+        e("s_mov_b32 s35, 0xfbfffbff")
     for t in range(16):
-        for q in range(4):
-            e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-        e("s_add_u32 s24, s24, 0x1000")
+        for q in range(2):
+            buf = 96 + 8 * t + 4 * q
+            for i in range(4):
+                a0 = 16 * t + 8 * q + 2 * i
+                e(f"v_accvgpr_read_b32 v{68 + 2 * (i & 1)}, a{a0}")
+                e(f"v_accvgpr_read_b32 v{69 + 2 * (i & 1)}, a{a0 + 1}")
+                e(f"{E.cvt} v{buf + i}, v{68 + 2 * (i & 1)}, v{69 + 2 * (i & 1)}")
+                if dt == "f16":
+                    e(f"v_pk_min_f16 v{buf + i}, v{buf + i}, s38")
+                    e(f"v_pk_max_f16 v{buf + i}, v{buf + i}, s35")
+            e(f"global_store_dwordx4 %17, v[{buf}:{buf + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else "") + PARK_POLICY)
+        e("s_add_u32 s24, s24, 0x800")
         e("s_addc_u32 s25, s25, 0")
-    # No vmcnt wait here: a store has read its data registers two wait states after it issued (the s_nop below covers the
-    # last one; the tiles are next written by the following view's LIN_IN MFMAs anyway), and the slot is not read before
-    # the reduce — whose entry guard drains the stores.  The 64 stores retire behind the next view's prologue.
+    # No vmcnt wait: the stores read their own buffer registers (written once each), the tiles are free for the next view's
+    # LIN_IN at once, and the slot is not read before the reduce — whose entry guard drains the stores.
     e("s_nop 1")
-    return L
+    return E.L
 
 
-def gen_viewreduce():
-    """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max), one pass per parked view, nine tiles' loads
-    in flight while a tile is combined.  Operands: %0-%15 x (pinned), %16 slot_0 base (s64), %17 NS-1 (s),
+def gen_viewreduce(dt):
+    """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max) from the 16-bit parks, one pass per parked view, all 16
+    tiles' loads (2 x dwordx4 each) in flight at once.  Operands: %0-%15 x (pinned), %16 slot_0 base (s64), %17 NS-1 (s),
     %18 combine_max (s), %19 lane*16 (v), %20 1/NS (v)."""
-    L = []
-    e = L.append
-
-    def loads(buf):
-        for q in range(4):
-            e(f"global_load_dwordx4 v[{buf + 4 * q}:{buf + 4 * q + 3}], %19, s[24:25]" + (f" offset:{q * 1024}" if q else ""))
-        e("s_add_u32 s24, s24, 0x1000")
-        e("s_addc_u32 s25, s25, 0")
+    E = Emit(dt)
+    e = E.e
 
     def combine_pass(op, scale=False):
-        NB, D = 10, 9
-        buf = lambda t: 96 + 16 * (t % NB)
-        for t in range(D):
-            loads(buf(t))
         for t in range(16):
-            if t + D < 16:
-                loads(buf(t + D))
-            e(f"s_waitcnt vmcnt({4 * min(D, 15 - t)})")
-            b = buf(t)
-            for i in range(16):
-                tmp = 68 + (i & 3)
-                e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
-                e(f"{op} v{tmp}, v{tmp}, v{b + i}")
-                if scale:
-                    e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
-                e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
+            for q in range(2):
+                buf = 96 + 8 * t + 4 * q
+                e(f"global_load_dwordx4 v[{buf}:{buf + 3}], %19, s[24:25]" + (f" offset:{q * 1024}" if q else "") + REDUCE_POLICY)
+            e("s_add_u32 s24, s24, 0x800")
+            e("s_addc_u32 s25, s25, 0")
+        for t in range(16):
+            e(f"s_waitcnt vmcnt({2 * (15 - t)})")
+            for j in range(8):                               # dword j of the tile: accumulators 16 t + 2 j, + 1
+                src = 96 + 8 * t + j
+                for half in range(2):
+                    tmp, acc = 68 + half, 16 * t + 2 * j + half
+                    if dt == "bf16":
+                        e(f"v_lshlrev_b32 v{70 + half}, 16, v{src}" if half == 0 else f"v_and_b32 v{70 + half}, 0xffff0000, v{src}")
+                    else:
+                        e(f"v_cvt_f32_f16 v{70 + half}, v{src}" if half == 0 else
+                          f"v_cvt_f32_f16_sdwa v{70 + half}, v{src} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+                    e(f"v_accvgpr_read_b32 v{tmp}, a{acc}")
+                    e(f"{op} v{tmp}, v{tmp}, v{70 + half}")
+                    if scale:
+                        e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
+                    e(f"v_accvgpr_write_b32 a{acc}, v{tmp}")
 
-    entry_guard(e)                                           # rule R1: the passes write v68-71 / v96-255
+    entry_guard(e)                                           # rule R1: the passes write v68-71 / v96-223
     e("s_nop 15")
     e("s_nop 15")
     e("s_mov_b64 s[26:27], %16")
@@ -684,7 +702,7 @@ def gen_viewreduce():
     e("s_cbranch_scc1 5b")
     e("6:")
     e("s_nop 7")
-    return L
+    return E.L
 
 
 M0_HOLD = 0        # instructions an LDS-DMA needs before the next write of M0: none, it reads M0 at issue (rule R3)
@@ -757,7 +775,7 @@ def audit_all(path):
         lines = re.findall(r'    "(.*)\\n\\t" \\', m.group(2))
         audit_statement(m.group(1), lines)
         n += 1
-    assert n == 8, f"audited {n} statements, expected 8"
+    assert n == 10, f"audited {n} statements, expected 10"
 
 
 def main():
@@ -767,8 +785,9 @@ def main():
         for dt, name, fn in (("bf16", "PNR_RESBLOCK_ASM_BF16", gen), ("f16", "PNR_RESBLOCK_ASM_F16", gen),
                              ("bf16", "PNR_XSTAGES_ASM_BF16", gen_xstages), ("f16", "PNR_XSTAGES_ASM_F16", gen_xstages),
                              ("bf16", "PNR_LINOUT_ASM_BF16", gen_linout), ("f16", "PNR_LINOUT_ASM_F16", gen_linout),
-                             (None, "PNR_VIEWSPILL_ASM", gen_viewspill), (None, "PNR_VIEWREDUCE_ASM", gen_viewreduce)):
-            lines = fn(dt) if dt else fn()
+                             ("bf16", "PNR_VIEWSPILL_ASM_BF16", gen_viewspill), ("f16", "PNR_VIEWSPILL_ASM_F16", gen_viewspill),
+                             ("bf16", "PNR_VIEWREDUCE_ASM_BF16", gen_viewreduce), ("f16", "PNR_VIEWREDUCE_ASM_F16", gen_viewreduce)):
+            lines = fn(dt)
             if "nobarrier" in DIAG:
                 lines = [l for l in lines if l != "s_barrier"]
             if "nowait" in DIAG:
