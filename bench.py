@@ -273,7 +273,7 @@ SECONDARY = [(DEFAULT, "fp16"), (DEFAULT, "fp32"),
              ("multiscale_cars_2view_128x128_k128+64", "fp16")]
 
 
-def stage_kernels_hbm(device, n_launch=5):
+def stage_kernels_hbm(device, n_launch=20):
     """SURVEY §8(d)'s HBM figure for the memory-bound stand-alone stages, measured: k_sample_coarse and k_composite
     (csrc/stage_kernels.hip; reference render/nerf.py:98-118,223-249) on the 120 000-ray DTU frame at K = 128, hipEvents on
     the stream they run on.  Algorithmic bytes per ray (DESIGN.md 4.3): sample_coarse reads near/far (8 B) and writes 4K;
