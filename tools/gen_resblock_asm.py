@@ -282,53 +282,61 @@ def xstages_core(E, baddr, cfg2, ring_lane, ring_wave, dma_off, bias_dword, allo
     """cfg2 & 0xff k-steps 'x += W . B' with B = the k-step image at LDS address `baddr` ([k-step][column group][lane] x 16 B,
     2 KiB per k-step), then (cfg2 bit 8) one bias k-step with B = (bias_dword, 0, 0, 0).  A k-step = 2 stages (row groups
     0-15, 16-31).  Enters with the cursor in s20-s29 / s[24:25] / s[36:37]; leaves s20 (st_slot) and s22 (ld_slot) advanced
-    and masked, all LDS reads drained except the first 8 fragments of the next stage (in A, tags A0-A7)."""
+    and masked, all LDS reads drained except the first 8 fragments of the next stage (in A, tags A0-A7), and the B pair of
+    the k-step BEHIND the last one it ran in v16-23 (its read-ahead: the folded head k-step of a projected block uses it).
+
+    Round 3: the k-steps run in PAIRS — four stages, i.e. once round the 4-slot ring, so the slot bases of fixed_bases()
+    hold for the whole loop (round 2 recomputed them after every stage: 11 scalar / vector instructions), and the two B pairs
+    alternate between v16-23 and v44-51 (round 2 copied the read-ahead pair down behind every k-step: s_nop 7 + 8 v_mov with
+    the MFMA pipe drained).  An odd k-step, and LIN_IN's C = 0 k-step, run singly and re-base afterwards."""
     e = E.e
 
-    def advance_slots():
-        e("s_add_u32 s20, s20, 1")
-        e("s_and_b32 s20, s20, 3")
-        e("s_add_u32 s22, s22, 1")
-        e("s_and_b32 s22, s22, 3")
-        e("v_mov_b32 v10, v11")                              # cur <- nxt
-        e("s_add_u32 s35, s20, 1")
-        e("s_and_b32 s35, s35, 3")
-        e("s_lshl_b32 s35, s35, 14")
-        e(f"v_add_u32 v11, s35, {ring_lane}")                # nxt
-        e("s_lshl_b32 s35, s22, 14")
-        e(f"s_add_u32 s40, s35, {ring_wave}")                # DMA destination of the stage being loaded
-
-    def mm_half(half, init=False):
+    def mm_half(half, init=False, b0=16):
         def mm(f):
             rg = 16 * half + f
-            return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {BX(cg)}, " + ("0" if init else X(rg, cg)) for cg in range(2)]
+            return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, v[{b0 + 4 * cg}:{b0 + 4 * cg + 3}], " + ("0" if init else X(rg, cg))
+                    for cg in range(2)]
         return mm
 
-    def kstep_body(init=False):
-        E.stage(mm_half(0, init), "v10", "v11", "s40")
-        advance_slots()
-        E.stage(mm_half(1, init), "v10", "v11", "s40")
-        advance_slots()
+    def advance2():
+        e("s_add_u32 s20, s20, 2")
+        e("s_and_b32 s20, s20, 3")
+        e("s_add_u32 s22, s22, 2")
+        e("s_and_b32 s22, s22, 3")
 
-    def next_b_and_kstep(init):
+    def single_kstep(init):
+        """One k-step on B = v16-23 at ring offsets 0, 1; the read-ahead pair comes back into v16-23; bases re-derived."""
         E.ds_read("N0", "ds_read_b128 v[44:47], v14")        # next k-step's B pair (the one past the last is never used)
         E.ds_read("N1", "ds_read_b128 v[48:51], v14 offset:1024")
         e("v_add_u32 v14, 0x800, v14")
-        kstep_body(init)
+        fixed_stage(E, 0, mm_half(0, init))
+        fixed_stage(E, 1, mm_half(1, init))
         E.need(["N0", "N1"])
         e("s_nop 7")                                         # the last MFMAs have read the old B
         for i in range(8):
             e(f"v_mov_b32 v{16 + i}, v{44 + i}")
+        advance2()
+        fixed_bases(E, ring_lane, ring_wave)
+
+    def pair_of_ksteps():
+        """Two k-steps = stages 0..3 of the ring: B(k) in v16-23, B(k+1) read ahead into v44-51 and used in place, B(k+2) read
+        ahead into v16-23 behind the first fragment of stage 2 (the last MFMA reading the old pair issued a fragment earlier)."""
+        E.ds_read("N0", "ds_read_b128 v[44:47], v14")
+        E.ds_read("N1", "ds_read_b128 v[48:51], v14 offset:1024")
+        fixed_stage(E, 0, mm_half(0))
+        fixed_stage(E, 1, mm_half(1))
+        E.need(["N0", "N1"])
+
+        def ahead():
+            E.ds_read("M0", "ds_read_b128 v[16:19], v14 offset:2048")
+            E.ds_read("M1", "ds_read_b128 v[20:23], v14 offset:3072")
+            e("v_add_u32 v14, 0x1000, v14")
+        fixed_stage(E, 2, mm_half(0, b0=44), {0: ahead})
+        fixed_stage(E, 3, mm_half(1, b0=44))
+        E.need(["M0", "M1"])
 
     e(f"s_and_b32 s34, {cfg2}, 0xff")                        # k-steps with B from the LDS image
-    e("s_lshl_b32 s35, s20, 14")
-    e(f"v_add_u32 v10, s35, {ring_lane}")                    # cur
-    e("s_add_u32 s35, s20, 1")
-    e("s_and_b32 s35, s35, 3")
-    e("s_lshl_b32 s35, s35, 14")
-    e(f"v_add_u32 v11, s35, {ring_lane}")                    # nxt
-    e("s_lshl_b32 s35, s22, 14")
-    e(f"s_add_u32 s40, s35, {ring_wave}")
+    fixed_bases(E, ring_lane, ring_wave)
     e(f"v_mov_b32 v14, {baddr}")
     e(f"v_mov_b32 v15, {dma_off}")
     E.ds_read("B0", "ds_read_b128 v[16:19], v14")            # B pair of the first k-step
@@ -342,19 +350,25 @@ def xstages_core(E, baddr, cfg2, ring_lane, ring_wave, dma_off, bias_dword, allo
         e(f"s_bitcmp1_b32 {cfg2}, 9")
         e("s_cbranch_scc0 6f")
         saved = list(E.reads)
-        next_b_and_kstep(True)
+        single_kstep(True)
         assert saved == E.reads
         e("s_sub_u32 s34, s34, 1")
         e("6:")
-    e("s_cmp_eq_u32 s34, 0")
+    e("s_cmp_lt_u32 s34, 2")
     e("s_cbranch_scc1 3f")
     E.loop_begin("1")
-    next_b_and_kstep(False)
-    e("s_sub_u32 s34, s34, 1")
-    e("s_cmp_lg_u32 s34, 0")
+    pair_of_ksteps()
+    e("s_sub_u32 s34, s34, 2")
+    e("s_cmp_ge_u32 s34, 2")
     e("s_cbranch_scc1 1b")
     E.loop_end()
     e("3:")
+    e("s_cmp_eq_u32 s34, 0")
+    e("s_cbranch_scc1 7f")
+    saved = list(E.reads)
+    single_kstep(False)                                      # the odd k-step
+    assert saved == E.reads
+    e("7:")
     e(f"s_bitcmp1_b32 {cfg2}, 8")                            # bias k-step requested?
     e("s_cbranch_scc0 4f")
     e(f"v_mov_b32 v16, {bias_dword}")
@@ -363,8 +377,10 @@ def xstages_core(E, baddr, cfg2, ring_lane, ring_wave, dma_off, bias_dword, allo
     e("v_mov_b32 v20, v16")
     e("s_nop 1")
     saved = list(E.reads)
-    kstep_body()
+    fixed_stage(E, 0, mm_half(0))
+    fixed_stage(E, 1, mm_half(1))
     assert saved == E.reads
+    advance2()
     e("4:")
 
 
