@@ -297,9 +297,19 @@ class PixelNeRFNet(torch.nn.Module):
         return [m.detach() for m in maps] if self.stop_encoder_grad else maps
 
     def workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self._ws
+        """Scratch of a native call, one buffer per (device, stream, host thread): the C ABI is re-entrant (the caller owns
+        the workspace), so two streams — or two threads — rendering through ONE net must not be handed the same bytes."""
+        import threading
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, int(torch.cuda.current_stream(idx).cuda_stream), threading.get_ident())
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
 
     # ------------------------------------------------------------------ per-point evaluation (backup2:155-282)
     def forward(self, xyz, coarse=True, viewdirs=None, far=False):

@@ -965,3 +965,32 @@ def test_fused_kernel_refuses_what_it_does_not_run(n_blocks, combine_layer, NS, 
     with pytest.raises((ValueError, RuntimeError)):
         build_renderer(spec)(net, torch.from_numpy(rays_np).cuda())
     torch.cuda.synchronize()
+
+
+def test_two_streams_through_one_net_do_not_share_a_workspace():
+    """pnr.h: every call is re-entrant, the caller owns the workspace — so PixelNeRFNet hands out one workspace per
+    (device, stream, thread).  Two streams rendering different multi-view batches through ONE net at the same time (the
+    multi-view workspace holds the parked per-view streams: sharing it would corrupt both) equal the sequential renders."""
+    from hip_util import build_net, build_renderer
+    import golden_util as gu
+    spec = dict(gu.CASES["full_ns3"]); spec.update(N=3000, Kc=64, Kf=0, Kfd=0, seed=55)
+    rays_np, poses = gu.make_inputs(spec)
+    rays = torch.from_numpy(rays_np).cuda()
+    a, b = rays[:, :1500].contiguous(), rays[:, 1500:].contiguous()
+    net = build_net(spec, poses, "cuda", "fp16")
+    rend = build_renderer(spec)
+    rend.forced_seed = 21
+    ref_a, ref_b = rend(net, a).coarse.rgb.clone(), rend(net, b).coarse.rgb.clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(3):                       # several rounds in flight on both streams
+        with torch.cuda.stream(s1):
+            o1 = rend(net, a).coarse.rgb
+        with torch.cuda.stream(s2):
+            o2 = rend(net, b).coarse.rgb
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    assert len(net._ws) >= 3                 # the default stream's and the two side streams'
+    for o1, o2 in outs:
+        assert torch.equal(o1, ref_a) and torch.equal(o2, ref_b)
