@@ -104,7 +104,10 @@ typedef struct pnr_params {
     int32_t precision;           /* PNR_F32 | PNR_BF16 | PNR_F16 */
     float depth_std;
     float freq_factor;           /* 1.5 (conf/default.conf:18) */
-    int32_t reserved[6];
+    int32_t train_tape_fp32;     /* training with precision = PNR_BF16: 0 = 16-bit tape (block inputs and fc_0 outputs kept as
+                                  * bf16 — the values the bf16-product GEMMs stage anyway: gradients are bit-identical to the
+                                  * fp32 tape's), 1 = fp32 tape */
+    int32_t reserved[5];
 } pnr_params;
 
 /* Explicit random draws, reference order (render/nerf.py:111,135,141,158).  A NULL member (or a NULL
@@ -228,7 +231,9 @@ typedef struct pnr_mlp_grads {
 
 /* Saved activations of one pnr_point_mlp_train_fwd call (what autograd would keep for ResnetFC.forward,
  * resnetfc.py:173-236) and the scratch its backward needs.  fp32 arithmetic, fp32 latent maps required. */
-uint64_t pnr_train_tape_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);
+uint64_t pnr_train_tape_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);   /* fp32 tape: the upper bound */
+/* the tape of a call with these params (precision = PNR_BF16 keeps a 16-bit tape: ~0.6 x the bytes) */
+uint64_t pnr_train_tape_bytes_for(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);
 uint64_t pnr_train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points);
 
 /* PixelNeRFNet.forward as pnr_point_mlp (same point naming), keeping the tape. */

@@ -49,7 +49,7 @@ class pnr_params(C.Structure):
     _fields_ = [
         ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("n_fine_depth", C.c_int32), ("white_bkgd", C.c_int32),
         ("lindisp", C.c_int32), ("use_code_viewdirs", C.c_int32), ("num_freqs", C.c_int32), ("precision", C.c_int32),
-        ("depth_std", C.c_float), ("freq_factor", C.c_float), ("reserved", C.c_int32 * 6),
+        ("depth_std", C.c_float), ("freq_factor", C.c_float), ("train_tape_fp32", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -100,6 +100,7 @@ PROTOTYPES = {
                                  C.POINTER(C.c_float), _i32, _i32, _f, _f, _f, _f, _f, _f, _i64, _i64, C.POINTER(pnr_noise), _u64,
                                  _i64, C.POINTER(pnr_outputs), _fp, _u64, _fp]),
     "pnr_train_tape_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
+    "pnr_train_tape_bytes_for": (_u64, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_train_bwd_workspace_bytes": (_u64, [C.POINTER(pnr_mlp), C.POINTER(pnr_views), _i64]),
     "pnr_point_mlp_train_fwd": (_i32, [C.POINTER(pnr_params), C.POINTER(pnr_mlp), C.POINTER(pnr_views), _fp, _fp, _i32,
                                        _fp, _fp, _i64, _i64, _fp, _fp, _u64, _fp]),

@@ -27,6 +27,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
                    const RayJob* job = nullptr);
 // train_f32.hip
 uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
+uint64_t train_tape_bytes_p(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P);
 int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
                         int64_t pts_per_obj, float* out, void* tape, uint64_t tape_bytes, hipStream_t s);
@@ -188,6 +189,12 @@ static int32_t point_args(const pnr_params* params, const pnr_mlp* mlp, const pn
 extern "C" uint64_t pnr_train_tape_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points) {
     if (!mlp || !views || n_points < 0) return 0;
     return train_tape_bytes(mlp, views, n_points);
+}
+
+extern "C" uint64_t pnr_train_tape_bytes_for(const pnr_params* params, const pnr_mlp* mlp, const pnr_views* views,
+                                             int64_t n_points) {
+    if (!params || !mlp || !views || n_points < 0) return 0;
+    return train_tape_bytes_p(params, mlp, views, n_points);
 }
 
 extern "C" uint64_t pnr_train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* views, int64_t n_points) {

@@ -342,9 +342,37 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2v));
 }
 
-template <bool RC>
-__device__ __forceinline__ void mh_fetch(const float* __restrict__ S, int ld, int x0, int X, int r0, int r1, float4 (&v)[4]) {
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// H16: the operand is stored as bf16 (the 16-bit tape of train_precision="bf16"): half the bytes, expanded to the fp32 values
+// mh_stage packs straight back — the staged LDS image is bit-identical to the one an fp32 copy of the same tensor gives,
+// because that copy would be rounded by the same v_cvt_pk_bf16_f32 here.
+template <bool RC, bool H16 = false>
+__device__ __forceinline__ void mh_fetch(const void* __restrict__ Sv, int ld, int x0, int X, int r0, int r1, float4 (&v)[4]) {
     const int t = threadIdx.x;
+    if (H16) {
+        const uint16_t* S = (const uint16_t*)Sv;
+        if (RC) {
+            const int x = min(x0 + (t >> 1), X - 1);
+            const uint4* p = (const uint4*)(S + (size_t)x * ld + r0 + 16 * (t & 1));
+            const uint4 a = p[0], b = p[1];
+            v[0] = make_float4(bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y));
+            v[1] = make_float4(bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w));
+            v[2] = make_float4(bf16_lo(b.x), bf16_hi(b.x), bf16_lo(b.y), bf16_hi(b.y));
+            v[3] = make_float4(bf16_lo(b.z), bf16_hi(b.z), bf16_lo(b.w), bf16_hi(b.w));
+        } else {
+            const int x = min(x0 + 4 * (t >> 3), X - 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = min(r0 + 4 * (t & 7) + i, r1 - 1);
+                const uint2 a = *(const uint2*)(S + (size_t)r * ld + x);
+                v[i] = make_float4(bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y));
+            }
+        }
+        return;
+    }
+    const float* S = (const float*)Sv;
     if (RC) {            // stored (X, R): thread -> row t/2, 16 consecutive r at 16*(t&1)
         const int x = min(x0 + (t >> 1), X - 1);
         const float* p = S + (size_t)x * ld + r0 + 16 * (t & 1);
@@ -412,11 +440,13 @@ __device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int 
     }
 }
 
-template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
+// A16 / B16 / M16: that operand / the mask is a bf16 tensor of the 16-bit tape; C16 (may be NULL): a bf16 copy of the result for
+// the tape, C may then be NULL (a result that only the tape keeps: fc_0's output).
+template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT, bool A16 = false, bool B16 = false, bool M16 = false>
 static __global__ void __launch_bounds__(256) k_mgemm_bf16(
-    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
-    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
-    int M, int N, int Rn, int r_per_split, size_t zs_c = 0, size_t zs_r = 0) {
+    const void* __restrict__ A, int lda, const void* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const void* __restrict__ Mk, int ldm, float* C, int ldc, float* __restrict__ rowsum,
+    int M, int N, int Rn, int r_per_split, size_t zs_c = 0, size_t zs_r = 0, uint16_t* __restrict__ C16 = nullptr, int ldc16 = 0) {
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -434,13 +464,13 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float4 va[4], vb[4];
     float rs = 0.f;
-    mh_fetch<A_RC>(A, lda, m0, M, rb, re, va);
-    mh_fetch<B_RC>(B, ldb, n0, N, rb, re, vb);
+    mh_fetch<A_RC, A16>(A, lda, m0, M, rb, re, va);
+    mh_fetch<B_RC, B16>(B, ldb, n0, N, rb, re, vb);
     mh_stage<A_RC, RELU_A, SPLIT>(As[0], va, rb, re);
     mh_stage<B_RC, RELU_B, false>(Bs[0], vb, rb, re);
     if (rb + 32 < re) {
-        mh_fetch<A_RC>(A, lda, m0, M, rb + 32, re, va);
-        mh_fetch<B_RC>(B, ldb, n0, N, rb + 32, re, vb);
+        mh_fetch<A_RC, A16>(A, lda, m0, M, rb + 32, re, va);
+        mh_fetch<B_RC, B16>(B, ldb, n0, N, rb + 32, re, vb);
     }
     __syncthreads();
     int buf = 0;
@@ -449,8 +479,8 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
             mh_stage<A_RC, RELU_A, SPLIT>(As[buf ^ 1], va, r0 + 32, re);
             mh_stage<B_RC, RELU_B, false>(Bs[buf ^ 1], vb, r0 + 32, re);
             if (r0 + 64 < re) {
-                mh_fetch<A_RC>(A, lda, m0, M, r0 + 64, re, va);
-                mh_fetch<B_RC>(B, ldb, n0, N, r0 + 64, re, vb);
+                mh_fetch<A_RC, A16>(A, lda, m0, M, r0 + 64, re, va);
+                mh_fetch<B_RC, B16>(B, ldb, n0, N, r0 + 64, re, vb);
             }
         }
 #pragma unroll
@@ -489,9 +519,19 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
                 if (SPLIT) {
                     C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
                 } else {
-                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
+                    if (Mk) {
+                        bool pos;
+                        if (M16) {               // bf16 tape value > 0: sign clear and not zero
+                            const uint16_t b16 = ((const uint16_t*)Mk)[(size_t)m * ldm + n];
+                            pos = (b16 & 0x8000u) == 0 && (b16 & 0x7fffu) != 0;
+                        } else {
+                            pos = ((const float*)Mk)[(size_t)m * ldm + n] > 0.f;
+                        }
+                        if (!pos) v = 0.f;
+                    }
                     if (R) v += R[(size_t)m * ldr + n];
-                    C[(size_t)m * ldc + n] = v;
+                    if (C) C[(size_t)m * ldc + n] = v;
+                    if (C16) C16[(size_t)m * ldc16 + n] = (uint16_t)(pk_bf16(v, 0.f) & 0xffffu);
                 }
             }
         }
@@ -919,21 +959,45 @@ struct Tape {
     float* o4;                       // (P, 4) head pre-activations
     int64_t rows[PNR_MAX_BLOCKS + 1];
     uint64_t total;
+    // 16-bit tape (train_precision = "bf16"): the block inputs and fc_0 outputs are kept as bf16 — exactly the values the
+    // bf16-product GEMMs stage anyway, so gradients are bit-identical to the fp32 tape's — and the fp32 residual stream the
+    // forward keeps adding to lives in two ping-pong buffers; A[n_blocks] (the head's input, read by non-MFMA kernels) is
+    // the buffer the forward finished in.
+    bool h16;
+    uint16_t* A16[PNR_MAX_BLOCKS + 1];
+    uint16_t* h16p[PNR_MAX_BLOCKS];
+    float* xw[2];
 };
 
 static inline uint64_t a256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
-static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void* base) {
+// the bf16-product mode keeps a 16-bit tape when every hidden GEMM takes the bf16 MFMA kernel (d_hidden a multiple of 32)
+static bool tape_is_16bit(const pnr_params* prm, const pnr_mlp* mlp) {
+    return prm && prm->precision == PNR_BF16 && prm->train_tape_fp32 == 0 && mlp->d_hidden >= 32 && mlp->d_hidden % 32 == 0;
+}
+
+static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void* base, bool h16 = false) {
     Tape t{};
+    t.h16 = h16;
     const int NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;   // padded row stride
     uint8_t* p = (uint8_t*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
     uint64_t off = 0;
     auto take = [&](uint64_t floats) { float* r = (float*)(p + off); off += a256(floats * 4); return r; };
+    auto take16 = [&](uint64_t halves) { uint16_t* r = (uint16_t*)(p + off); off += a256(halves * 2); return r; };
     t.zx = take((uint64_t)NS * P * E);
+    if (h16) {
+        t.xw[0] = take((uint64_t)NS * P * H);
+        t.xw[1] = take((uint64_t)NS * P * H);
+    }
     for (int b = 0; b <= mlp->n_blocks; ++b) {
         t.rows[b] = (NS > 1 && b >= mlp->combine_layer) ? P : (int64_t)NS * P;
-        t.A[b] = take((uint64_t)t.rows[b] * H);
-        if (b < mlp->n_blocks) t.h[b] = take((uint64_t)t.rows[b] * H);
+        if (h16) {
+            t.A16[b] = take16((uint64_t)t.rows[b] * H);
+            if (b < mlp->n_blocks) t.h16p[b] = take16((uint64_t)t.rows[b] * H);
+        } else {
+            t.A[b] = take((uint64_t)t.rows[b] * H);
+            if (b < mlp->n_blocks) t.h[b] = take((uint64_t)t.rows[b] * H);
+        }
     }
     t.xpre = NS > 1 ? take((uint64_t)NS * P * H) : nullptr;
     t.o4 = take((uint64_t)P * 4);
@@ -943,6 +1007,9 @@ static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void*
 
 uint64_t train_tape_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
     return carve_tape(mlp, vw, P, nullptr).total;
+}
+uint64_t train_tape_bytes_p(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
+    return carve_tape(mlp, vw, P, nullptr, tape_is_16bit(prm, mlp)).total;
 }
 
 // Scratch for the weight gradients (carved from the backward workspace): every row split of a dW GEMM writes its own
@@ -981,6 +1048,31 @@ static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
 }
 
 static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0; }
+
+// 16-bit-tape forms of a bf16-product GEMM: X16 (the activations operand as bf16, instead of X), Mk16 (the relu mask as bf16,
+// instead of Mk), Y16 (a bf16 copy of the result; Y may then be NULL).  Only the bf16 MFMA kernel takes them.
+struct G16 { const uint16_t* X16; const uint16_t* Mk16; uint16_t* Y16; };
+
+template <bool RELU_X, bool TRANS_W>
+static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
+                      const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
+    if (M == 0) return PNR_OK;
+    if (!(N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(W, ldw))) return PNR_E_UNSUPPORTED;
+    dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+    const void* Xp = g.X16 ? (const void*)g.X16 : (const void*)X;
+    const void* Mp = g.Mk16 ? (const void*)g.Mk16 : (const void*)Mk;
+#define PNR_G16_LAUNCH(A16, M16)                                                                                       \
+    hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false, A16, false, M16>), grid, dim3(256), 0, s, Xp, ldx, \
+                       (const void*)W, ldw, b, R, ldr, Mp, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0, (size_t)0,    \
+                       (size_t)0, g.Y16, ldy)
+    if (g.X16 && g.Mk16) PNR_G16_LAUNCH(true, true);
+    else if (g.X16) PNR_G16_LAUNCH(true, false);
+    else if (g.Mk16) PNR_G16_LAUNCH(false, true);
+    else PNR_G16_LAUNCH(false, false);
+#undef PNR_G16_LAUNCH
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
 
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
@@ -1046,7 +1138,7 @@ __global__ void k_reduce_parts(const float* __restrict__ part, int nz, size_t zs
 // request takes k_col_sums.
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
-                      int N, int K, hipStream_t s, int half, const DetWs& ws) {
+                      int N, int K, hipStream_t s, int half, const DetWs& ws, const uint16_t* X16 = nullptr) {
     if ((!dW && !db) || M == 0) return PNR_OK;
     const size_t zs_w = (size_t)N * K, zs_b = (size_t)N;
     // rows per split: the kernel's natural slice, enlarged until the splits fit the scratch
@@ -1087,7 +1179,8 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
         return finish(nz);
     }
     const bool mfma_shape = N >= 32 && K >= 32;
-    const bool use_half = half && mfma_shape && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && al16(X, ldx);
+    const bool use_half = half && mfma_shape && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && (X16 ? true : al16(X, ldx));
+    if (X16 && !(use_half && half == 1)) return PNR_E_UNSUPPORTED;      // the 16-bit tape is read by the bf16 MFMA kernel only
     const bool head = !mfma_shape && N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0;
     nz = splits_for(mfma_shape ? 1024 : head ? 256 : 2048, &rows);
     float* pb = pw + (size_t)nz * zs_w;
@@ -1099,6 +1192,10 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
             hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
+        else if (use_half && X16)
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>), grid, dim3(256), 0, s,
+                               (const void*)dY, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
+                               (const void*)nullptr, 0, pw, K, pbk, N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half)
             hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
@@ -1121,14 +1218,90 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
 
 #define PNR_TRY(expr) do { int32_t _rc = (expr); if (_rc) return _rc; } while (0)
 
+// bf16 copy of a fp32 tensor (the residual stream behind a view reduction, or lin_in's output when no lin_z follows)
+static __global__ void k_to_bf16(const float* __restrict__ x, int64_t n, uint16_t* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (uint16_t)(pk_bf16(x[i], 0.f) & 0xffffu);
+}
+
+// The taped forward with the 16-bit tape (train_precision = "bf16", see Tape): same GEMMs, same operands after rounding; the
+// fp32 residual stream ping-pongs between t.xw[0] / t.xw[1], every GEMM that produces a block input also writes its bf16 copy.
+static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
+                                      int64_t pts_per_obj, float* out, Tape& t, hipStream_t s) {
+    const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
+    const int E = (L + Din + 3) & ~3;
+    const int nb = mlp->n_blocks, cl = mlp->combine_layer;
+    const int n_lin_z = cl < nb ? cl : nb;
+    const int64_t MV = (int64_t)NS * P;
+    if (MV > 0x7fffffff) return PNR_E_SHAPE;
+    int64_t tot = MV * (L + Din);
+    hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
+                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
+    PNR_LAUNCH_CHECK();
+    auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
+        hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    };
+    auto combine = [&](float* dst) -> int32_t {
+        int64_t per_view = P * H;
+        hipLaunchKernelGGL(k_combine_f32, dim3((unsigned)((per_view + 255) / 256)), dim3(256), 0, s, t.xpre, NS,
+                           per_view, mlp->combine_type, dst);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    };
+    int cur = 0;
+    const bool comb0 = NS > 1 && cl == 0;
+    // lin_in (Din is not a multiple of 32: the fp32 kernels, fp32 operand zx)
+    PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, comb0 ? t.xpre : t.xw[cur], H,
+                                MV, H, Din, s, 1)));
+    if (comb0) PNR_TRY(combine(t.xw[cur]));
+    if (!(L > 0 && 0 < n_lin_z)) PNR_TRY(to16(t.xw[cur], t.rows[0] * H, t.A16[0]));     // block 0's input is final already
+    for (int b = 0; b < nb; ++b) {
+        const int64_t M = t.rows[b];
+        float* x = t.xw[cur];
+        if (L > 0 && b < n_lin_z) {
+            // x += lin_z[b](z): fp32 operand zx; result in place + its bf16 copy = the block input
+            const G16 g{nullptr, nullptr, t.A16[b]};
+            if (L % 32 == 0 && al16(t.zx, E)) {
+                PNR_TRY((gemm16<false, false>(g, t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], x, H, nullptr, 0, x, H, M, H, L, s)));
+            } else {
+                PNR_TRY((gemm<false, false>(t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], x, H, nullptr, 0, x, H, M, H, L, s, 1)));
+                PNR_TRY(to16(x, M * H, t.A16[b]));
+            }
+        }
+        // h = fc_0(relu(x)): operand and result live on the tape only
+        PNR_TRY((gemm16<true, false>(G16{t.A16[b], nullptr, t.h16p[b]}, nullptr, H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0,
+                                     nullptr, 0, nullptr, H, M, H, H, s)));
+        const bool comb = NS > 1 && b + 1 == cl;
+        float* dst = comb ? t.xpre : t.xw[cur ^ 1];
+        // x' = x + fc_1(relu(h)): fp32 for the chain, bf16 copy = the next block's input (unless lin_z / the reduction rewrite it)
+        const bool next_final = !comb && !(L > 0 && b + 1 < n_lin_z);
+        PNR_TRY((gemm16<true, false>(G16{t.h16p[b], nullptr, next_final ? t.A16[b + 1] : nullptr}, nullptr, H, mlp->fc1_w[b], H,
+                                     mlp->fc1_b[b], x, H, nullptr, 0, dst, H, M, H, H, s)));
+        cur ^= 1;
+        if (comb) {
+            PNR_TRY(combine(t.xw[cur]));
+            if (!(L > 0 && b + 1 < n_lin_z)) PNR_TRY(to16(t.xw[cur], t.rows[b + 1] * H, t.A16[b + 1]));
+        }
+    }
+    t.A[nb] = t.xw[cur];                 // the head reads the fp32 stream (non-MFMA kernels)
+    PNR_TRY((gemm<true, false>(t.A[nb], H, mlp->lin_out_w, H, mlp->lin_out_b, nullptr, 0, nullptr, 0, t.o4, 4, P, 4, H, s, 0)));
+    hipLaunchKernelGGL(k_out_act, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, t.o4, P, out);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
 int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw, PointSrc src, int64_t P,
                         int64_t pts_per_obj, float* out, void* tape, uint64_t tape_bytes, hipStream_t s) {
-    if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
+    const bool t16 = tape_is_16bit(prm, mlp);
+    if (tape_bytes < train_tape_bytes_p(prm, mlp, vw, P)) return PNR_E_WORKSPACE;
     const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
     const int E = (L + Din + 3) & ~3;      // row stride of zx (16-byte rows for the vector loads)
     const int nb = mlp->n_blocks, cl = mlp->combine_layer;
     if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
-    Tape t = carve_tape(mlp, vw, P, tape);
+    Tape t = carve_tape(mlp, vw, P, tape, t16);
+    if (t16) return point_train_fwd_tape16(prm, mlp, vw, src, P, pts_per_obj, out, t, s);
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
@@ -1169,13 +1342,15 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                   int64_t pts_per_obj, const float* out, const float* d_out, void* tape, uint64_t tape_bytes,
                   const pnr_mlp_grads* gr, float* const* d_latent, float* d_xyz, float* d_z, void* workspace,
                   uint64_t ws_bytes, hipStream_t s) {
-    if (tape_bytes < train_tape_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
+    const bool t16 = tape_is_16bit(prm, mlp);
+    if (tape_bytes < train_tape_bytes_p(prm, mlp, vw, P)) return PNR_E_WORKSPACE;
     if (ws_bytes < train_bwd_workspace_bytes(mlp, vw, P)) return PNR_E_WORKSPACE;
     const int NS = vw->n_views, L = mlp->d_latent, Din = mlp->d_in, H = mlp->d_hidden;
     const int E = (L + Din + 3) & ~3;
     const int nb = mlp->n_blocks, cl = mlp->combine_layer;
     if (NS > 1 && cl >= nb) return PNR_E_UNSUPPORTED;
-    Tape t = carve_tape(mlp, vw, P, tape);
+    Tape t = carve_tape(mlp, vw, P, tape, t16);
+    if (t16) t.A[nb] = t.xw[nb & 1];          // where the forward's fp32 stream ended (point_train_fwd_tape16)
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
@@ -1201,10 +1376,19 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     bool dz_started = false;
     for (int b = nb - 1; b >= 0; --b) {
         const int64_t M = t.rows[b];
+        if (t16) {      // the same four GEMMs, the tape operands / masks read as the bf16 the fp32-tape form would round them to
+            PNR_TRY((grad_w<true>(dx, H, nullptr, H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws, t.h16p[b])));
+            PNR_TRY((gemm16<false, true>(G16{nullptr, t.h16p[b], nullptr}, dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, nullptr, H,
+                                         dh, H, M, H, H, s)));
+            PNR_TRY((grad_w<true>(dh, H, nullptr, H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws, t.A16[b])));
+            PNR_TRY((gemm16<false, true>(G16{nullptr, t.A16[b], nullptr}, dh, H, mlp->fc0_w[b], H, nullptr, dx, H, nullptr, H, dx, H,
+                                         M, H, H, s)));
+        } else {
         PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws)));
         PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s, half)));
         PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws)));
         PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half)));
+        }
         if (L > 0 && b < n_lin_z) {
             PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half, dws)));
             if (want_dz) {

@@ -79,6 +79,8 @@ class PixelNeRFNet(torch.nn.Module):
         # operand splits, fp32-class results, 1.5x faster) or "bf16" (plain bf16 products — like the reference's use_amp);
         # fp32 accumulation / tape / gradients in every mode
         self.train_precision = conf.get_string("train_precision", "fp32")
+        # tape of the "bf16" mode: "auto" = 16-bit (same gradients, ~0.6 x the bytes), "fp32" = the fp32 tape
+        self.train_tape = conf.get_string("train_tape", "auto")
         # one source view with one small latent map: stream W_z . Lat instead of W_z and skip the gather (pnr.h,
         # pnr_pack_mlp_projected); off = always the general gather + lin_z kernel path
         self.project_latent = conf.get_bool("project_latent", os.environ.get("PNR_PROJECT_LATENT", "1") != "0")

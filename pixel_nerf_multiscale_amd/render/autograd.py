@@ -12,7 +12,9 @@ points (csrc/train_f32.hip) — no PyTorch arithmetic on the per-point data:
 Gradients reach the MLP weights, the encoder's latent maps (and through them the ResNet trunk, which stays
 a PyTorch module) and — because nerf.py:287-289 does not detach the depth-guided samples — the coarse depth
 through the fine pass's sample positions.  Arithmetic is fp32 (the reference trains in fp32);
-`net.train_precision = "bf16"` runs the GEMM products on the bf16 MFMA with fp32 accumulation, fp32 tape and fp32
+`net.train_precision = "bf16"` runs the GEMM products on the bf16 MFMA with fp32 accumulation, a 16-bit tape (the block inputs
+and fc_0 outputs kept as the bf16 values those GEMMs stage anyway: gradients bit-identical to an fp32 tape's, which
+`net.train_tape = "fp32"` selects) and fp32
 results (the counterpart of the reference's AMP switch, train/train.py:385-398).
 """
 import ctypes as C
@@ -54,6 +56,12 @@ def _grads_struct_from(hdr, grads):
     return g
 
 
+def _train_params(net):
+    prm = net.params_struct(None, net.train_precision)
+    prm.train_tape_fp32 = 1 if getattr(net, "train_tape", "auto") == "fp32" else 0
+    return prm
+
+
 class PointMLP(torch.autograd.Function):
     """out (n_points, 4) = PixelNeRFNet.forward at points named by rays+z (a, b = rays (N,8), z (N,K)) or
     explicitly (a, b = xyz (SB*P,3), viewdirs (SB*P,3)).  Differentiable in b=z / a=xyz, the MLP parameters
@@ -76,7 +84,8 @@ class PointMLP(torch.autograd.Function):
         if n_points % v.n_objs:
             raise ValueError("points do not divide evenly over the encoded objects")
         prm = hdr["prm"]
-        tape = torch.empty(int(N.lib.pnr_train_tape_bytes(C.byref(m), C.byref(v), n_points)), dtype=torch.uint8, device=dev)
+        tape = torch.empty(int(N.lib.pnr_train_tape_bytes_for(C.byref(prm), C.byref(m), C.byref(v), n_points)), dtype=torch.uint8,
+                           device=dev)
         out = torch.empty(n_points, 4, device=dev)
         args = (N.ptr(a), N.ptr(b), K, None, None) if rays_mode else (None, None, 0, N.ptr(a), N.ptr(b))
         N.check(N.lib.pnr_point_mlp_train_fwd(C.byref(prm), C.byref(m), C.byref(v), *args, n_points,
@@ -201,7 +210,7 @@ def _header(net, mlp, rays_mode):
     return dict(d_in=mlp.d_in, d_latent=mlp.d_latent, d_hidden=mlp.d_hidden, d_out=mlp.d_out, n_blocks=mlp.n_blocks,
                 combine_layer=mlp.combine_layer, combine_type=mlp.combine_type,
                 n_lin_z=len(mlp.lin_z) if mlp.d_latent else 0, n_params=len(mlp_tensors(mlp)),
-                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=net.params_struct(None, net.train_precision))
+                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=_train_params(net))
 
 
 def point_mlp_rays(net, mlp, rays, z):

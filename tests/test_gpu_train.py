@@ -369,3 +369,46 @@ def test_latent_map_gradients_are_run_to_run_identical(NS, SB, lat):
     assert float(a.abs().max()) > 0 and torch.equal(a, b)
     # 300 rays x 48 samples = 14400 points per object = 57 blocks of 256 points per view: the reduction really spans slices
     assert a.shape == base[0].shape
+
+
+@pytest.mark.parametrize("name", ["full_ns1", "full_ns3", "full_multiscale_ns2", "tiny_ns2_codeview", "tiny_max_combine"])
+def test_bf16_mode_16bit_tape_gives_the_fp32_tapes_gradients_bit_for_bit(name):
+    """train_precision='bf16' keeps the block inputs and fc_0 outputs on the tape as bf16 — the values its GEMMs stage
+    anyway (same v_cvt_pk_bf16_f32 rounding, relu commutes with it, the relu masks only look at the sign) — so every
+    output and every gradient equals the fp32-tape run of the same mode bit for bit, at ~0.6x the tape bytes."""
+    import ctypes as C
+    from pixel_nerf_multiscale_amd import _native as N
+
+    def run(tape):
+        fx, spec, net, rend = hu.setup(name)
+        net.train()
+        net.train_precision, net.train_tape = "bf16", tape
+        maps = [torch.from_numpy(x).cuda().requires_grad_(True) for x in gu.make_latents(spec)]
+        net.encoder.set_latents(maps)
+        out = rend(net, torch.from_numpy(fx["rays"]).cuda(), want_weights=True)
+        G = {k: torch.from_numpy(v).cuda() for k, v in gu.make_loss_weights(spec).items()}
+        loss = sum((out[t].rgb * G[f"{t}_rgb"]).sum() + (out[t].weights * G[f"{t}_weights"]).sum() for t in ("coarse", "fine"))
+        loss.backward()
+        grads = {f"{w}.{k}": p.grad.clone() for w, mlp in (("coarse", net.mlp_coarse), ("fine", net.mlp_fine)) if mlp is not None
+                 for k, p in mlp.named_parameters()}
+        grads.update({f"latent.{i}": m.grad.clone() for i, m in enumerate(maps)})
+        prm = net.params_struct(None, "bf16")
+        prm.train_tape_fp32 = 1 if tape == "fp32" else 0
+        v, _ = net.views_struct("fp32")
+        m, _ = net.mlp_struct(net.mlp_coarse, "fp32")
+        nbytes = N.lib.pnr_train_tape_bytes_for(C.byref(prm), C.byref(m), C.byref(v), 4096 * v.n_objs)
+        return out.fine.rgb.detach().clone(), grads, nbytes
+
+    rgb16, g16, b16 = run("auto")
+    rgb32, g32, b32 = run("fp32")
+    assert torch.equal(rgb16, rgb32)
+    for k in g32:
+        if k.startswith("latent.") and "multiscale" in name:
+            # multi-level maps are beyond the LDS: their gradient is still scattered with atomics (sum order = arrival order)
+            assert torch.allclose(g16[k], g32[k], rtol=1e-4, atol=1e-6 * float(g32[k].abs().max())), k
+        else:
+            assert torch.equal(g16[k], g32[k]), k
+    if "full" in name:
+        assert b16 < 0.85 * b32       # d_hidden 512: the 16-bit tape applies (0.58x with one view; the fp32 per-view stream of a multi-view net stays)
+    else:
+        assert b16 <= b32
