@@ -5,8 +5,8 @@ reference's single-process nn.DataParallel(dim=1) (reference render/nerf.py:367-
 Rays are independent units, so a batch (SB, B, 8) is cut along B into contiguous ranges, one per rank (every object's
 rays alike, as DataParallel(dim=1) does); every rank holds the same packed weights and latents (loaded / encoded
 locally), renders its range with the in-kernel noise keyed by the ray's index in the UNSHARDED batch, and ONE collective
-per call — an in-place all_gather of (SB * B/world, 4) fp32 [rgb, depth] records that the render launch itself wrote into
-this rank's slice of the buffer — reassembles the pixels on every rank.  With the same seed the gathered batch is
+per call — an all_gather of (SB * B/world, 4) fp32 [rgb, depth] records that the render launch itself wrote into the
+collective's input buffer — reassembles the pixels on every rank.  With the same seed the gathered batch is
 bit-identical to the 1-GPU one.  Training is data-parallel instead (one batch per rank, allreduce_gradients below).
 """
 import torch
@@ -33,8 +33,8 @@ class ShardedRenderer:
     renderer; __call__(rays (SB, B, 8)) returns the full (rgb (SB,B,3), depth (SB,B)) on every rank.  gather() is the
     general form: any list of per-ray outputs, packed into one (SB * rays/world, sum(widths)) fp32 message.
     render_into(rays, base, seed, obj_stride, out (SB, n, tot)) -> bool, when given and returning True, has written the
-    packed records straight into `out` — this rank's slice of the gather buffer — so the collective runs in place with
-    no copy before it (NeRFRenderer.forward_packed: the render launch writes them)."""
+    packed records straight into `out` — the collective's input buffer — so there is no copy in front of the collective
+    (NeRFRenderer.forward_packed: the render launch writes them)."""
 
     def __init__(self, render_shard, group=None, base_seed=None, render_into=None):
         self.render_shard = render_shard
@@ -81,7 +81,7 @@ class ShardedRenderer:
     def gather(self, rays, widths):
         """rays (SB, B, 8), cut along B: rank k renders rays[:, lo_k:hi_k] of EVERY object (nn.DataParallel(dim=1),
         reference render/nerf.py:367-371) with the generator keyed by the rays' indices in the unsharded batch.  ONE
-        all_gather of (SB * ceil(B/world), sum(widths)) fp32 per rank, in place on the buffer the render launch wrote;
+        all_gather of (SB * ceil(B/world), sum(widths)) fp32 per rank, straight from the buffer the render launch wrote;
         returns the full (SB, B, w) / (SB, B) tensors on every rank (views of the gathered buffer when SB == 1)."""
         assert rays.dim() == 3, "rays (SB, B, 8)"
         SB, B = rays.shape[0], rays.shape[1]
@@ -91,8 +91,12 @@ class ShardedRenderer:
         self.frame_idx += 1
         tot = int(sum(widths))
         obj_stride = B if SB > 1 else 0
+        # the rank's own records get their own buffer at world > 1: an all_gather whose input aliases its output is legal for
+        # NCCL / RCCL but is the one thing about this path that cannot be rehearsed on a one-card box, and the collective copies
+        # the rank's 1/world share either way
         full = torch.empty(self.world, SB * per, tot, device=rays.device, dtype=torch.float32)
-        mine = full[self.rank]                                       # (SB * per, tot): rows [0, SB * n) are this rank's records
+        mine = full[0] if self.world == 1 else torch.empty(SB * per, tot, device=rays.device, dtype=torch.float32)
+        # (SB * per, tot): rows [0, SB * n) are this rank's records
         if n > 0:
             shard = rays[:, lo:hi] if SB == 1 else rays[:, lo:hi].contiguous()
             slab = mine[: SB * n].view(SB, n, tot)
@@ -112,7 +116,7 @@ class ShardedRenderer:
                 dist.all_gather_into_tensor(host.view(-1), mine.cpu().view(-1), group=self.group)
                 full = host.to(rays.device)
             else:
-                dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=self.group)     # in place: input = output[rank]
+                dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=self.group)
         if SB == 1:
             recs = full.view(self.world * per, tot)[:B].unsqueeze(0)                            # (1, B, tot), a view
         else:

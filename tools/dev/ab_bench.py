@@ -12,7 +12,7 @@ step = {}
 for rnd in range(3):
     for l in libs:
         env = dict(os.environ, PNR_LIB=os.path.join(ROOT, l))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--cpu-rays", "0", "--secondary-steps", "0"] + wl,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--cpu-rays", "0", "--secondary-steps", "0", "--precision", os.environ.get("PNR_AB_PRECISION", "bf16")] + wl,
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         res[l].append(d["roofline"]["kernel_ms"])
