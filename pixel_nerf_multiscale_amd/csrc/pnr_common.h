@@ -273,21 +273,24 @@ __device__ __forceinline__ float4 composite_ray(const float* zr, const float4* c
     float carry = 1.0f;
     float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, aw = 0.f;
     // the next 64-sample segment's loads are issued before this segment's scan (same arithmetic, one round trip hidden)
+    // z_{k+1} is the neighbouring lane's z_k (one DPP wave shift, no second load); lane 63's neighbour is lane 0 of the next segment
     int k = lane;
     bool act = k < K;
     float zk = act ? ld_f<NT>(zr + k) : 0.f;
-    float zn = (k + 1 < K) ? ld_f<NT>(zr + k + 1) : far;       // delta_K = far - z_K
     float4 c = act ? ld_f4<NT>(cr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k2 = k0 + 64 + lane;
         const bool act2 = k2 < K;
-        float zk2 = 0.f, zn2 = far;
+        float zk2 = 0.f;
         float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k0 + 64 < K) {
             zk2 = act2 ? ld_f<NT>(zr + k2) : 0.f;
-            zn2 = (k2 + 1 < K) ? ld_f<NT>(zr + k2 + 1) : far;
             c2 = act2 ? ld_f4<NT>(cr + k2) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float zn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zk), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+        const float z_next_seg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zk2), 0));
+        if (lane == 63) zn = z_next_seg;
+        if (!(k + 1 < K)) zn = far;                             // delta_K = far - z_K
         float delta = zn - zk;
         float alpha = act ? 1.0f - expf(-delta * fmaxf(c.w, 0.0f)) : 0.0f;
         float tr = act ? (1.0f - alpha) + 1e-10f : 1.0f;
@@ -298,7 +301,7 @@ __device__ __forceinline__ float4 composite_ray(const float* zr, const float4* c
         carry *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
         if (act && wr) wr[k] = w;
         ar = fmaf(w, c.x, ar); ag = fmaf(w, c.y, ag); ab = fmaf(w, c.z, ab); ad = fmaf(w, zk, ad); aw += w;
-        k = k2; act = act2; zk = zk2; zn = zn2; c = c2;
+        k = k2; act = act2; zk = zk2; c = c2;
     }
     ar = wave_sum_l(ar, lane); ag = wave_sum_l(ag, lane); ab = wave_sum_l(ab, lane); ad = wave_sum_l(ad, lane);
     aw = wave_sum_l(aw, lane);
