@@ -114,6 +114,32 @@ __device__ __forceinline__ float wave_scan_mul_l(float v, int lane) {
     return v;
 }
 
+// The compositing's scan and sums on DPP row shifts / row broadcasts (gfx9 wave64: shifts by 1, 2, 4, 8 inside each row of 16
+// lanes, then lane 15 of a row into the next row, then lane 31 into the upper half) — VALU moves with no LDS crossbar
+// traffic and no lane index at all.  Lanes a step has no source for keep `ident`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_mul_dpp(float v) {        // inclusive product over lanes 0 .. l
+    v *= dpp_f<0x111, 0xf>(1.0f, v);      // row_shr:1
+    v *= dpp_f<0x112, 0xf>(1.0f, v);      // row_shr:2
+    v *= dpp_f<0x114, 0xf>(1.0f, v);      // row_shr:4
+    v *= dpp_f<0x118, 0xf>(1.0f, v);      // row_shr:8
+    v *= dpp_f<0x142, 0xa>(1.0f, v);      // row_bcast:15 into rows 1, 3
+    v *= dpp_f<0x143, 0xc>(1.0f, v);      // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {             // the sum of all 64 lanes, in every lane
+    v += dpp_f<0x111, 0xf>(0.0f, v);
+    v += dpp_f<0x112, 0xf>(0.0f, v);
+    v += dpp_f<0x114, 0xf>(0.0f, v);
+    v += dpp_f<0x118, 0xf>(0.0f, v);
+    v += dpp_f<0x142, 0xa>(0.0f, v);
+    v += dpp_f<0x143, 0xc>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ---------------------------------------------------------------- cameras / projection
 // One source view after PixelNeRFNet.encode (models.py.backup2:121-150).
 struct Cam {
@@ -294,17 +320,16 @@ __device__ __forceinline__ float4 composite_ray(const float* zr, const float4* c
         float delta = zn - zk;
         float alpha = act ? 1.0f - expf(-delta * fmaxf(c.w, 0.0f)) : 0.0f;
         float tr = act ? (1.0f - alpha) + 1e-10f : 1.0f;
-        float incl = wave_scan_mul_l(tr, lane);
-        float excl = shfl_at(incl, lane > 0 ? lane - 1 : 0);
-        if (lane == 0) excl = 1.0f;
+        float incl = wave_scan_mul_dpp(tr);
+        float excl = dpp_f<0x138 /* wave_shr:1 */, 0xf>(1.0f, incl);       // lane 0 has no source: 1
         float w = alpha * (carry * excl);
         carry *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
         if (act && wr) wr[k] = w;
         ar = fmaf(w, c.x, ar); ag = fmaf(w, c.y, ag); ab = fmaf(w, c.z, ab); ad = fmaf(w, zk, ad); aw += w;
         k = k2; act = act2; zk = zk2; c = c2;
     }
-    ar = wave_sum_l(ar, lane); ag = wave_sum_l(ag, lane); ab = wave_sum_l(ab, lane); ad = wave_sum_l(ad, lane);
-    aw = wave_sum_l(aw, lane);
+    ar = wave_sum_dpp(ar); ag = wave_sum_dpp(ag); ab = wave_sum_dpp(ab); ad = wave_sum_dpp(ad);
+    aw = wave_sum_dpp(aw);
     if (white_bkgd) { float bg = 1.0f - aw; ar = ar + bg; ag = ag + bg; ab = ab + bg; }
     return make_float4(ar, ag, ab, ad);
 }
