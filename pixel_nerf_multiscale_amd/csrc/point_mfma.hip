@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             asm volatile("" : "+s"(d32));
             return (int64_t)((uint32_t)num / d32);
         }
+        asm volatile("" : "+s"(den));          // (the 64-bit expansion has a 32-bit fast path with a hoistable reciprocal too)
         return num / den;
     };
     // ---------------- this workgroup's points [p_begin, p_end): whole rays in a fused render launch (so that a ray is composited
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         // lane (g, c) serves points (cg, c), cg = 0, 1: tile-local index wv*32 + 16 cg + c.  Source-view index of such a point
         // for view pass v (one object: v itself, wave-uniform):
         auto view_of = [&](int cc, int cg, int vv) __attribute__((always_inline)) -> int {
-            if (a.vw.n_objs == 1) return vv;
+            if (!flag(a.vw.n_objs - 1)) return vv;          // tested where it is used (see flag)
             int li = tile * TILE_PTS + wv * 32 + 16 * cg + cc;
             li = li < n_loc ? li : n_loc - 1;
             const int64_t gi = p_begin + li;

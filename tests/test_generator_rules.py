@@ -41,3 +41,35 @@ def test_audit_rejects_rule_violations():
         g.audit_statement("m0b", ok + ["s_mov_b32 m0, s40", "global_load_lds_dwordx4 v15, s[24:25]", "s_nop 7", "s_nop 7"])
     # operands (%N) and accumulator tiles are the compiler's business, not the audit's
     g.audit_statement("operands", ["v_mov_b32 %0, 1", "v_accvgpr_write_b32 a3, %1"])
+
+
+def test_fused_kernel_keeps_nothing_in_scratch(tmp_path):
+    """The compiler half of rule R1: a value hipcc keeps in scratch across the statements comes back through a
+    scratch_load that can be pending when a statement starts (the fp16 race) and whose s_waitcnt vmcnt(0) drains the LDS-DMA
+    in flight.  The C++ around the statements is written so that no instantiation of the fused kernel has any scratch
+    traffic at all (launch-uniform tests and divisors are formed where they are used: flag(), lane_id(), div_pts in
+    point_mfma.hip).  This compiles the kernel to ISA and checks exactly that."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    src = os.path.join(ROOT, "pixel_nerf_multiscale_amd", "csrc", "point_mfma.hip")
+    out = tmp_path / "point_mfma.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text().splitlines()
+    kernels, name = {}, None
+    for ln in text:
+        s = ln.split(";")[0].strip()
+        if s.endswith(":") and "k_point_mfma" in s and not s.startswith("."):
+            name = s[:-1]
+            kernels[name] = []
+        elif s.startswith(".size") and name and name in s:
+            name = None
+        elif name:
+            kernels[name].append(s)
+    assert len(kernels) == 4, list(kernels)            # {bf16, fp16} x {one view, several views}
+    for k, body in kernels.items():
+        bad = [s for s in body if s.startswith(("scratch_", "buffer_load", "buffer_store")) and not s.startswith("buffer_wbl2")]
+        assert not bad, (k, bad[:4])
