@@ -121,6 +121,29 @@ def pmc_traffic(workload, precision):
         return None, None
 
 
+def pmc_clock(workload, precision):
+    """Effective shader clock (GHz) the dominant kernel held in the committed PMC pass of this command: GRBM_GUI_ACTIVE
+    (summed over the 8 XCDs) / 8 / the dispatch's duration in the same pass (MI355X_MICROARCH.md 'DVFS give-back').  Same
+    gating as pmc_traffic: only for the sources this library was built from.  The kernel is power-limited: the 2.5 PFLOP/s
+    peak of roofline.peak assumes the 2.4 GHz maximum clock, so frac x 2.4 / clock is the fraction of the MFMA issue rate
+    the kernel reaches at the clock the chip lets it run at."""
+    if workload != DEFAULT or precision != "bf16":
+        return None
+    try:
+        vals, src = {}, None
+        for line in open(os.path.join(ROOT, "profiles", "latest_pmc_bench_default.txt")):
+            parts = line.split()
+            if line.startswith("# sources:"):
+                src = line.split(":", 1)[1].strip()
+            if len(parts) >= 4 and parts[1] in ("GRBM_GUI_ACTIVE", "KERNEL_NS"):
+                vals[parts[1]] = float(parts[3].split("=")[1])
+        if src != source_hash():
+            return None
+        return vals["GRBM_GUI_ACTIVE"] / 8.0 / vals["KERNEL_NS"], vals["KERNEL_NS"]
+    except Exception:
+        return None
+
+
 def build(workload, precision, device, rank_rays_scale=1, seed=0):
     """Random-init network of the reference architecture + synthetic latents/cameras/rays (no dataset, no checkpoint)."""
     import golden_util as gu
@@ -377,6 +400,15 @@ def main():
     traffic, traffic_src = pmc_traffic(args.workload, args.precision) if world == 1 else (None, None)
     rec["roofline"]["traffic"] = traffic
     rec["roofline"]["traffic_source"] = traffic_src
+    clk = pmc_clock(args.workload, args.precision) if world == 1 else None
+    if clk:
+        # context, not the judged fraction (`frac` stays this run's achieved / the 2.4-GHz peak): the committed PMC pass's own
+        # launch duration and clock — the same launch priced against the MFMA rate at the clock it ran at
+        ghz, ns = clk
+        in_pass = rec["roofline"]["flops_per_launch"] / (ns * 1e-9) / 1e12
+        rec["roofline"]["pmc_pass"] = {"kernel_ms": round(ns * 1e-6, 4), "clock_ghz": round(ghz, 3), "achieved": round(in_pass, 1),
+                                       "frac_of_peak": round(in_pass / rec["roofline"]["peak"], 4),
+                                       "frac_of_peak_at_that_clock": round(in_pass / (rec["roofline"]["peak"] * ghz / 2.4), 4)}
     out = {
         # BASELINE.json's metric on its config; the other shapes (--workload) are labelled as what they are
         "metric": ("rendered rays/sec (128 samples/ray), SRN chairs 1-view" if args.workload == DEFAULT

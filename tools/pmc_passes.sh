@@ -19,4 +19,10 @@ for p in ("p1","p2","p3"):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in sorted(acc.items()):
             print(p, k, "n=%d mean=%.6g" % (len(v), sum(v)/len(v)))
+# duration of the same dispatches in the pass that holds GRBM_GUI_ACTIVE: effective clock = GRBM_GUI_ACTIVE / 8 / duration
+# (MI355X_MICROARCH.md 'DVFS give-back'; the counter is summed over the 8 XCDs)
+for f in glob.glob("$OUT/p1/**/*kernel_trace.csv", recursive=True):
+    d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "k_point_mfma" in r["Kernel_Name"]]
+    if d:
+        print("p1 KERNEL_NS n=%d mean=%.6g" % (len(d), sum(d)/len(d)))
 PY
