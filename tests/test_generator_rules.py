@@ -68,8 +68,26 @@ def test_fused_kernel_keeps_nothing_in_scratch(tmp_path):
         elif s.startswith(".size") and name and name in s:
             name = None
         elif name:
-            kernels[name].append(s)
+            kernels[name].append("#ASMSTART" if "#ASMSTART" in ln else "#ASMEND" if "#ASMEND" in ln else s)
     assert len(kernels) == 4, list(kernels)            # {bf16, fp16} x {one view, several views}
     for k, body in kernels.items():
         bad = [s for s in body if s.startswith(("scratch_", "buffer_load", "buffer_store")) and not s.startswith("buffer_wbl2")]
         assert not bad, (k, bad[:4])
+        # the pinned accumulator tiles a[0:255] belong to the statements: no compiler v_accvgpr_* move outside them
+        # (cdna_hip_programming.md §5.7 item 4)
+        inside, moved = False, []
+        for s in body:
+            if "#ASMSTART" in s:
+                inside = True
+            elif "#ASMEND" in s:
+                inside = False
+            elif not inside and s.startswith("v_accvgpr"):
+                moved.append(s)
+        assert not moved, (k, moved[:4])
+    # the code-object metadata agrees: no VGPR spilled (SGPRs spill into VGPR lanes, not memory)
+    meta = [ln.strip() for ln in text if ".vgpr_spill_count:" in ln or (".name:" in ln and "k_point_mfma" in ln)]
+    names = [i for i, ln in enumerate(text) if ".name:" in ln and "k_point_mfma" in ln]
+    assert len(names) == 4, meta
+    for i in names:
+        spill = next(ln for ln in text[i:i + 12] if ".vgpr_spill_count:" in ln)
+        assert spill.split(":")[1].strip() == "0", (text[i].strip(), spill.strip())
