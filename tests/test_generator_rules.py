@@ -1,5 +1,5 @@
 """The hand-scheduled statements of the fused kernel are generated (tools/gen_resblock_asm.py).  CPU checks: the committed
-.inc is what the generator produces today, and the generator's audit enforces the statement rules R1-R3 of its header —
+.inc is what the generator produces today, and the generator's audit enforces the statement rules R1-R4 of its header —
 R1 is the root cause of round 2's fp16 race (a pending compiler load landing in a register the statement had already written)."""
 import importlib.util
 import os
@@ -39,6 +39,11 @@ def test_audit_rejects_rule_violations():
     g.audit_statement("m0", ok + ["s_mov_b32 m0, s40", "s_nop 0", "global_load_lds_dwordx4 v15, s[24:25]", "s_mov_b32 m0, s39"])
     with pytest.raises(AssertionError, match="R3"):      # no wait state between the M0 write and the DMA
         g.audit_statement("m0b", ok + ["s_mov_b32 m0, s40", "global_load_lds_dwordx4 v15, s[24:25]", "s_nop 7", "s_nop 7"])
+    # R4: the compiler pads nothing behind ';;#ASMEND' — the last MFMA needs its wait states inside the statement
+    mf = ok + ["v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[128:131], a[0:3]"]
+    with pytest.raises(AssertionError, match="R4"):
+        g.audit_statement("mfma_tail", mf + ["s_nop 7"])
+    g.audit_statement("mfma_tail_ok", mf + ["s_nop 15", "s_nop 7"])
     # operands (%N) and accumulator tiles are the compiler's business, not the audit's
     g.audit_statement("operands", ["v_mov_b32 %0, 1", "v_accvgpr_write_b32 a3, %1"])
 

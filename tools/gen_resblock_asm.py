@@ -44,6 +44,10 @@ Statement rules (audited by main() on the generated text, see audit_statement):
              not, still lands every byte at the original destination (tools/dev/ubench/waw_ubench.hip part C,
              profiles/r03_waw_ubench.txt) — so M0 need not be held behind a piece.  The other direction is a documented
              hazard: `s_mov_b32 m0` -> LDS-DMA needs one wait state (s_nop 0).
+  R4 MFMA    hipcc pads nothing across ';;#ASMEND': the last MFMA's result must be readable by whatever the compiler puts
+             next (a v_accvgpr_read of a tile it parks, a VALU on an output).  An 8-pass MFMA's D wants 12 wait states
+             before a non-MFMA reader, a 16-pass one 18+; every statement that issues an MFMA ends with at least
+             MFMA_EXIT_STATES (24) states behind its last one (s_nop k = k + 1 states, any other instruction 1).
 Registers used inside (all declared clobbered): v10-13 slot read bases, v14 address temp, v15 DMA lane offset, v16-23 B pair of the
 x-stages, v40-55 / v72-87 the two chunk accumulators (VGPR-form MFMA), v44-51 next B pair (x-stages), v60-67 relu(h)
 fragments, v68-71 temps, v96-127 A-fragment ring (8 x 4), v128-255 relu(x) fragments (16 k-steps x 2 column groups x 4),
@@ -745,7 +749,7 @@ def _vdest(line):
 
 
 def audit_statement(name, lines):
-    """Rules R1-R3 of the header on the final text of one statement (straight-line scan: branches only skip forward or loop
+    """Rules R1-R4 of the header on the final text of one statement (straight-line scan: branches only skip forward or loop
     over stage bodies that satisfy the rules themselves)."""
     seen_vm = seen_lgkm = False
     first_write = None
@@ -782,6 +786,20 @@ def audit_statement(name, lines):
                     break
             for k in range(i + 1, min(i + 1 + M0_HOLD, len(lines))):
                 assert not lines[k].startswith("s_mov_b32 m0"), f"{name}: R3 — M0 rewritten {k - i} instruction(s) behind a DMA"
+
+
+    # R4: wait states behind the last MFMA
+    mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+    if mf:
+        states = 0
+        for l in lines[mf[-1] + 1:]:
+            if l.endswith(":") or l.startswith((";", "//")):
+                continue
+            states += int(l.split()[1]) + 1 if l.startswith("s_nop") else 1
+        assert states >= MFMA_EXIT_STATES, f"{name}: R4 — only {states} wait states behind the last MFMA"
+
+
+MFMA_EXIT_STATES = 24
 
 
 def audit_all(path):
