@@ -13,9 +13,25 @@ __global__ void k_sample_coarse(const float* __restrict__ rays, int64_t n_rays, 
                                 float* __restrict__ z_out) {
     const int q_per_ray = (Kc + 3) >> 2;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rays * q_per_ray) return;
-    const int64_t ray = idx / q_per_ray;
-    const int k0 = (int)(idx % q_per_ray) * 4;
+    const int64_t tot = n_rays * q_per_ray;
+    if (idx >= tot) return;
+    // (ray, quad) of the thread: the kernel is VALU-bound (Philox + the sample arithmetic), and a 64-bit division and
+    // remainder per thread were a quarter of its instructions — shift for a power of two, 32-bit division below 2^31 threads
+    int64_t ray;
+    int kq;
+    if ((q_per_ray & (q_per_ray - 1)) == 0) {
+        const int sh = 31 - __builtin_clz((unsigned)q_per_ray);
+        ray = idx >> sh;
+        kq = (int)(idx & (q_per_ray - 1));
+    } else if (tot < 0x7fffffffLL) {
+        const uint32_t r32 = (uint32_t)idx / (uint32_t)q_per_ray;
+        ray = r32;
+        kq = (int)((uint32_t)idx - r32 * (uint32_t)q_per_ray);
+    } else {
+        ray = idx / q_per_ray;
+        kq = (int)(idx - ray * q_per_ray);
+    }
+    const int k0 = kq * 4;
     const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
     float u[4];
     if (noise) {

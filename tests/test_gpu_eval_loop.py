@@ -62,7 +62,14 @@ def test_evaluate_two_objects_resume_and_lut(tmp_path):
     lut.write_text("cat0 obj000 0\ncat1 obj001 0\n")
     calls = []
     orig = rend.render_image
-    rend.render_image = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    rendered = []
+
+    def recording(*a, **k):
+        calls.append(1)
+        res = orig(*a, **k)
+        rendered.append(res[0].detach().clone())
+        return res
+    rend.render_image = recording
     m2 = evalio.evaluate(net, rend, data, out, viewlist=str(lut), verbose=False)
     rend.render_image = orig
     rows = [x.split() for x in open(os.path.join(out, "finish.txt")).read().split("\n") if x]
@@ -91,9 +98,8 @@ def test_evaluate_two_objects_resume_and_lut(tmp_path):
     idat = raw[raw.index(b"IDAT") + 4:]
     n = struct.unpack(">I", raw[raw.index(b"IDAT") - 4:raw.index(b"IDAT")])[0]
     px = np.frombuffer(zlib.decompress(idat[:n]), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H, W, 3)
-    net.encode(data[1]["images"][:1].cuda()[None], data[1]["poses"][:1].cuda()[None], torch.tensor(focal)[None].cuda())
-    rend.forced_seed = 777
-    rgb, _ = rend.render_image(net, data[1]["poses"][2], W, H, focal, data.z_near, data.z_far)
-    # (re-encoding goes through MIOpen again, whose convolution algorithm choice may differ between calls: allow the last bit)
-    want = evalio.quantize_uint8(rgb.clamp(0, 1).cpu().numpy()).astype(np.int32)
-    assert np.abs(px.astype(np.int32) - want).max() <= 1 and (px == want).mean() >= 0.98
+    # the frame evaluate() rendered for that file (object 1's targets are views 1, 2, 3: the second call of pass 2) — not a
+    # second encode + render: the trunk goes through MIOpen, whose algorithm choice (and with it the latent's last bits) may
+    # differ from call to call
+    want = evalio.quantize_uint8(rendered[1].clamp(0, 1).reshape(H, W, 3).cpu().numpy())
+    assert np.array_equal(px, want)
