@@ -353,14 +353,14 @@ __device__ __forceinline__ void mh_fetch(const void* __restrict__ Sv, int ld, in
     const int t = threadIdx.x;
     if (H16) {
         const uint16_t* S = (const uint16_t*)Sv;
-        if (RC) {
-            const int x = min(x0 + (t >> 1), X - 1);
-            const uint4* p = (const uint4*)(S + (size_t)x * ld + r0 + 16 * (t & 1));
-            const uint4 a = p[0], b = p[1];
-            v[0] = make_float4(bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y));
-            v[1] = make_float4(bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w));
-            v[2] = make_float4(bf16_lo(b.x), bf16_hi(b.x), bf16_lo(b.y), bf16_hi(b.y));
-            v[3] = make_float4(bf16_lo(b.z), bf16_hi(b.z), bf16_lo(b.w), bf16_hi(b.w));
+        if (RC) {        // a row's 32-r slice is 64 B: 4 lanes x 16 B, 64 rows per instruction (v[2i], v[2i+1]: row t/4 + 64 i)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int x = min(x0 + (t >> 2) + 64 * i, X - 1);
+                const uint4 a = *(const uint4*)(S + (size_t)x * ld + r0 + 8 * (t & 3));
+                v[2 * i] = make_float4(bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y));
+                v[2 * i + 1] = make_float4(bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w));
+            }
         } else {
             const int x = min(x0 + 4 * (t >> 3), X - 4);
 #pragma unroll
@@ -373,11 +373,14 @@ __device__ __forceinline__ void mh_fetch(const void* __restrict__ Sv, int ld, in
         return;
     }
     const float* S = (const float*)Sv;
-    if (RC) {            // stored (X, R): thread -> row t/2, 16 consecutive r at 16*(t&1)
-        const int x = min(x0 + (t >> 1), X - 1);
-        const float* p = S + (size_t)x * ld + r0 + 16 * (t & 1);
+    if (RC) {            // stored (X, R): a row's 32-r slice is 128 B = 8 lanes x 16 B, 32 rows per instruction (v[i]: row t/8 + 32 i).
+        // (One thread reading its own 64 contiguous bytes — 2 lanes per row — issued 4x the L1 requests of this mapping: the
+        // forward / dX GEMMs were bound by the request rate, 1.7-1.9 TB/s: profiles/r03_pmc_train_mem.txt.)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *(const float4*)(p + 4 * i);
+        for (int i = 0; i < 4; ++i) {
+            const int x = min(x0 + (t >> 3) + 32 * i, X - 1);
+            v[i] = *(const float4*)(S + (size_t)x * ld + r0 + 4 * (t & 7));
+        }
     } else {             // stored (R, X): thread -> 4 r's at 4*(t&7), 4 x's at 4*(t>>3)
         const int x = min(x0 + 4 * (t >> 3), X - 4);
 #pragma unroll
@@ -393,7 +396,7 @@ __device__ __forceinline__ uint32_t pk_bf16_lo(float f0, float f1, uint32_t hi) 
     return pk_bf16(f0 - __builtin_bit_cast(float, hi << 16), f1 - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 
-template <bool RC, bool RELU, bool ZERO_TAIL>
+template <bool RC, bool RELU, bool ZERO_TAIL, bool H16 = false>
 __device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int r0, int r1, uint16_t (*TL)[40] = nullptr) {
     const int t = threadIdx.x;
     // the loads above are unconditional and complete HERE (not earlier: hipcc would otherwise sink them into the
@@ -406,20 +409,30 @@ __device__ __forceinline__ void mh_stage(uint16_t (*T)[40], float4 (&v)[4], int 
 #pragma unroll
         for (int e = 0; e < 16; ++e) f[e] = fmaxf(f[e], 0.f);
     }
-    if (RC) {
+    if (RC && H16) {     // f[8 i + j]: row t/4 + 64 i, r = 8 (t&3) + j   (mh_fetch<true, true>)
         if (ZERO_TAIL) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) f[e] = (r0 + 16 * (t & 1) + e < r1) ? f[e] : 0.f;
+            for (int e = 0; e < 16; ++e) f[e] = (r0 + 8 * (t & 3) + (e & 7) < r1) ? f[e] : 0.f;
         }
-        uint4 lo = {pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
-        uint4 hi = {pk_bf16(f[8], f[9]), pk_bf16(f[10], f[11]), pk_bf16(f[12], f[13]), pk_bf16(f[14], f[15])};
-        *(uint4*)&T[t >> 1][16 * (t & 1)] = lo;
-        *(uint4*)&T[t >> 1][16 * (t & 1) + 8] = hi;
-        if (TL) {       // residual image (bf16x3)
-            uint4 l0 = {pk_bf16_lo(f[0], f[1], lo.x), pk_bf16_lo(f[2], f[3], lo.y), pk_bf16_lo(f[4], f[5], lo.z), pk_bf16_lo(f[6], f[7], lo.w)};
-            uint4 l1 = {pk_bf16_lo(f[8], f[9], hi.x), pk_bf16_lo(f[10], f[11], hi.y), pk_bf16_lo(f[12], f[13], hi.z), pk_bf16_lo(f[14], f[15], hi.w)};
-            *(uint4*)&TL[t >> 1][16 * (t & 1)] = l0;
-            *(uint4*)&TL[t >> 1][16 * (t & 1) + 8] = l1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint4 w = {pk_bf16(f[8 * i], f[8 * i + 1]), pk_bf16(f[8 * i + 2], f[8 * i + 3]), pk_bf16(f[8 * i + 4], f[8 * i + 5]),
+                             pk_bf16(f[8 * i + 6], f[8 * i + 7])};
+            *(uint4*)&T[(t >> 2) + 64 * i][8 * (t & 3)] = w;
+        }
+    } else if (RC) {     // f[4 i + j]: row t/8 + 32 i, r = 4 (t&7) + j       (mh_fetch<true, false>)
+        if (ZERO_TAIL) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f[e] = (r0 + 4 * (t & 7) + (e & 3) < r1) ? f[e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint2 w = {pk_bf16(f[4 * i], f[4 * i + 1]), pk_bf16(f[4 * i + 2], f[4 * i + 3])};
+            *(uint2*)&T[(t >> 3) + 32 * i][4 * (t & 7)] = w;
+            if (TL) {       // residual image (bf16x3)
+                const uint2 wl = {pk_bf16_lo(f[4 * i], f[4 * i + 1], w.x), pk_bf16_lo(f[4 * i + 2], f[4 * i + 3], w.y)};
+                *(uint2*)&TL[(t >> 3) + 32 * i][4 * (t & 7)] = wl;
+            }
         }
     } else {
         if (ZERO_TAIL) {
@@ -450,8 +463,23 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    // XCD-aware tile order (1-D grid, mgemm_grid below).  Workgroup ids go round the 8 XCDs, each with its own L2: the tiles
+    // that share an operand — the N tiles of one 128-row block of the activations, or all (m, n) tiles of one reduction
+    // split — get consecutive slots on ONE XCD, so the operand is fetched from HBM once instead of once per tile
+    // (measured before: activations re-read 1.8-2.7x, profiles/r03_pmc_train_mem.txt).
+    const int gx = (M + 127) / 128, gy = (N + 127) / 128;
+    int bx, by, bz = 0;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int G = SPLIT ? gx * gy : gy;
+        const int NG = SPLIT ? (Rn + r_per_split - 1) / r_per_split : gx;
+        const int grp = (slot / G) * 8 + xcd, tg = slot % G;
+        if (grp >= NG) return;
+        if (SPLIT) { bz = grp; bx = tg % gx; by = tg / gx; }
+        else { bx = grp; by = tg; }
+    }
+    const int m0 = bx * 128, n0 = by * 128;
+    const int rb = SPLIT ? bz * r_per_split : 0;
     const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     const int lr = lane >> 5, lc = lane & 31;
@@ -466,8 +494,8 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     float rs = 0.f;
     mh_fetch<A_RC, A16>(A, lda, m0, M, rb, re, va);
     mh_fetch<B_RC, B16>(B, ldb, n0, N, rb, re, vb);
-    mh_stage<A_RC, RELU_A, SPLIT>(As[0], va, rb, re);
-    mh_stage<B_RC, RELU_B, false>(Bs[0], vb, rb, re);
+    mh_stage<A_RC, RELU_A, SPLIT, A16>(As[0], va, rb, re);
+    mh_stage<B_RC, RELU_B, false, B16>(Bs[0], vb, rb, re);
     if (rb + 32 < re) {
         mh_fetch<A_RC, A16>(A, lda, m0, M, rb + 32, re, va);
         mh_fetch<B_RC, B16>(B, ldb, n0, N, rb + 32, re, vb);
@@ -476,8 +504,8 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     int buf = 0;
     for (int r0 = rb; r0 < re; r0 += 32) {
         if (r0 + 32 < re) {
-            mh_stage<A_RC, RELU_A, SPLIT>(As[buf ^ 1], va, r0 + 32, re);
-            mh_stage<B_RC, RELU_B, false>(Bs[buf ^ 1], vb, r0 + 32, re);
+            mh_stage<A_RC, RELU_A, SPLIT, A16>(As[buf ^ 1], va, r0 + 32, re);
+            mh_stage<B_RC, RELU_B, false, B16>(Bs[buf ^ 1], vb, r0 + 32, re);
             if (r0 + 64 < re) {
                 mh_fetch<A_RC, A16>(A, lda, m0, M, r0 + 64, re, va);
                 mh_fetch<B_RC, B16>(B, ldb, n0, N, r0 + 64, re, vb);
@@ -489,12 +517,15 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
             bf16x8 a1 = *(const bf16x8*)&As[buf][wm + 32 + lc][16 * s + 8 * lr];
             bf16x8 b0 = *(const bf16x8*)&Bs[buf][wn + lc][16 * s + 8 * lr];
             bf16x8 b1 = *(const bf16x8*)&Bs[buf][wn + 32 + lc][16 * s + 8 * lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            // operands swapped: the tile comes out TRANSPOSED — lane lc holds row m, its registers 4 consecutive n per group
+            // of four (n = 8 (e >> 2) + 4 lr + (e & 3)) — so the epilogue moves 16-byte rows of C / R / the mask instead of
+            // single elements (64 -> 16 memory instructions per thread and tensor; same products, same sums)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
         }
-        if (rowsum && blockIdx.y == 0 && t < 128) {       // bias gradient = row sums of the (bf16-rounded) A tile
+        if (rowsum && by == 0 && t < 128) {       // bias gradient = row sums of the (bf16-rounded) A tile
 #pragma unroll
             for (int r = 0; r < 32; r += 2) {
                 uint32_t p = *(const uint32_t*)&As[buf][t][r];
@@ -504,39 +535,70 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
         __syncthreads();
         buf ^= 1;
     }
+    // 16-byte accesses need 16-byte rows: every leading dimension a multiple of 4 elements, every base aligned (N % 4 == 0 is
+    // the launcher's condition already); otherwise element by element
+    const bool vec = ((ldc | ldr | ldm | ldc16) & 3) == 0 && (((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0 &&
+                     ((uintptr_t)Mk & (M16 ? 7 : 15)) == 0 && ((uintptr_t)C16 & 7) == 0 && (zs_c & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm + 32 * i + lc;
+        if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn + 32 * j + lc;
-            if (n >= N) continue;
-            const float bn = bias ? bias[n] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
-                if (m >= M) continue;
-                float v = acc[i][j][e] + bn;
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn + 32 * j + 8 * q + 4 * lr;          // n .. n + 3 (N % 4 == 0: all four or none)
+                if (n >= N) continue;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (bias) {
+                    if (vec) { const float4 b4 = *(const float4*)(bias + n); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+                    else { for (int u = 0; u < 4; ++u) v[u] += bias[n + u]; }
+                }
                 if (SPLIT) {
-                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
-                } else {
-                    if (Mk) {
-                        bool pos;
-                        if (M16) {               // bf16 tape value > 0: sign clear and not zero
-                            const uint16_t b16 = ((const uint16_t*)Mk)[(size_t)m * ldm + n];
-                            pos = (b16 & 0x8000u) == 0 && (b16 & 0x7fffu) != 0;
-                        } else {
-                            pos = ((const float*)Mk)[(size_t)m * ldm + n] > 0.f;
-                        }
-                        if (!pos) v = 0.f;
+                    float* dst = C + bz * zs_c + (size_t)m * ldc + n;       // this split's own slice (grad_w)
+                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int u = 0; u < 4; ++u) dst[u] = v[u]; }
+                    continue;
+                }
+                if (Mk) {
+                    if (M16) {               // bf16 tape value > 0: sign clear and not zero
+                        const uint16_t* mp = (const uint16_t*)Mk + (size_t)m * ldm + n;
+                        uint16_t b16[4];
+                        if (vec) { const uint2 w = *(const uint2*)mp; b16[0] = w.x & 0xffffu; b16[1] = w.x >> 16; b16[2] = w.y & 0xffffu; b16[3] = w.y >> 16; }
+                        else { for (int u = 0; u < 4; ++u) b16[u] = mp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (!((b16[u] & 0x8000u) == 0 && (b16[u] & 0x7fffu) != 0)) v[u] = 0.f;
+                    } else {
+                        const float* mp = (const float*)Mk + (size_t)m * ldm + n;
+                        float mk[4];
+                        if (vec) { const float4 w = *(const float4*)mp; mk[0] = w.x; mk[1] = w.y; mk[2] = w.z; mk[3] = w.w; }
+                        else { for (int u = 0; u < 4; ++u) mk[u] = mp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (!(mk[u] > 0.f)) v[u] = 0.f;
                     }
-                    if (R) v += R[(size_t)m * ldr + n];
-                    if (C) C[(size_t)m * ldc + n] = v;
-                    if (C16) C16[(size_t)m * ldc16 + n] = (uint16_t)(pk_bf16(v, 0.f) & 0xffffu);
+                }
+                if (R) {
+                    const float* rp = R + (size_t)m * ldr + n;
+                    if (vec) { const float4 w = *(const float4*)rp; v[0] += w.x; v[1] += w.y; v[2] += w.z; v[3] += w.w; }
+                    else { for (int u = 0; u < 4; ++u) v[u] += rp[u]; }
+                }
+                if (C) {
+                    float* dst = C + (size_t)m * ldc + n;
+                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int u = 0; u < 4; ++u) dst[u] = v[u]; }
+                }
+                if (C16) {
+                    uint16_t* dst = C16 + (size_t)m * ldc16 + n;
+                    const uint2 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+                    if (vec) *(uint2*)dst = w;
+                    else { dst[0] = w.x & 0xffffu; dst[1] = w.x >> 16; dst[2] = w.y & 0xffffu; dst[3] = w.y >> 16; }
                 }
             }
-        }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
-        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+    }
+    if (rowsum && by == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[bz * zs_r + m0 + t] = rs;
         else atomicAdd(rowsum + m0 + t, rs);
     }
 }
@@ -1053,12 +1115,15 @@ static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0
 // instead of Mk), Y16 (a bf16 copy of the result; Y may then be NULL).  Only the bf16 MFMA kernel takes them.
 struct G16 { const uint16_t* X16; const uint16_t* Mk16; uint16_t* Y16; };
 
+// 1-D grid of k_mgemm_bf16 (its XCD-aware tile order): n_groups rounded up to the 8 XCDs, `group` tiles each
+static inline dim3 mgemm_grid(int64_t n_groups, int group) { return dim3((unsigned)(((n_groups + 7) / 8) * 8 * group)); }
+
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
                       const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
     if (M == 0) return PNR_OK;
     if (!(N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(W, ldw))) return PNR_E_UNSUPPORTED;
-    dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+    const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
     const void* Xp = g.X16 ? (const void*)g.X16 : (const void*)X;
     const void* Mp = g.Mk16 ? (const void*)g.Mk16 : (const void*)Mk;
 #define PNR_G16_LAUNCH(A16, M16)                                                                                       \
@@ -1084,8 +1149,8 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
             hipLaunchKernelGGL((k_mgemm_bf16x3<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
                                ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
         else
-            hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
-                               ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+            hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), mgemm_grid((M + 127) / 128, (N + 127) / 128),
+                               dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
@@ -1193,11 +1258,13 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half && X16)
-            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>), grid, dim3(256), 0, s,
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>),
+                               mgemm_grid(nz, ((N + 127) / 128) * ((K + 127) / 128)), dim3(256), 0, s,
                                (const void*)dY, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
                                (const void*)nullptr, 0, pw, K, pbk, N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half)
-            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>),
+                               mgemm_grid(nz, ((N + 127) / 128) * ((K + 127) / 128)), dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
         else
