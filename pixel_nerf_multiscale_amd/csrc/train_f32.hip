@@ -216,6 +216,112 @@ __device__ __forceinline__ void mg_stage(float (*T)[132], float (&v)[8]) {
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2v f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2v));
+}
+
+// ------------------------------------------------------------------ shared by the three MFMA tile GEMMs below
+// 1-D grid with an XCD-aware tile order.  Workgroup ids go round the 8 XCDs, each with its own L2: the tiles that share an
+// operand — the N tiles of one 128-row block of the activations, or all (m, n) tiles of one reduction split — get
+// consecutive slots on ONE XCD, so the operand is fetched from HBM once instead of once per tile (measured before:
+// activations re-read 1.8-2.7x, after: 1.0x; profiles/r03_pmc_train_mem.txt).  n_groups rounded up to the 8 XCDs.
+static inline dim3 mgemm_grid(int64_t n_groups, int group) { return dim3((unsigned)(((n_groups + 7) / 8) * 8 * group)); }
+
+template <bool SPLIT>
+__device__ __forceinline__ bool mgemm_tile(int M, int N, int Rn, int r_per_split, int& bx, int& by, int& bz) {
+    const int gx = (M + 127) / 128, gy = (N + 127) / 128;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int G = SPLIT ? gx * gy : gy;
+    const int NG = SPLIT ? (Rn + r_per_split - 1) / r_per_split : gx;
+    const int grp = (slot / G) * 8 + xcd, tg = slot % G;
+    bx = by = bz = 0;
+    if (grp >= NG) return false;
+    if (SPLIT) { bz = grp; bx = tg % gx; by = tg / gx; }
+    else { bx = grp; by = tg; }
+    return true;
+}
+
+// Epilogue of a 128 x 128 workgroup tile whose MFMAs ran with the operands SWAPPED (mfma(b, a)): the 32 x 32 tiles come out
+// transposed — lane lc holds row m, its registers 4 consecutive n per group of four (n = 8 (e >> 2) + 4 lr + (e & 3)) — so
+// C, the residual R, the relu mask and the bf16 copy move as 16-byte (8-byte) rows instead of single elements: 16 instead of
+// 64 memory instructions per thread and tensor (the element-wise form was 30-45 % of the forward / dX launch).  Same
+// products, same sums.  16-byte accesses need every leading dimension % 4 == 0 and aligned bases; otherwise by element.
+template <bool SPLIT, bool M16>
+__device__ __forceinline__ void mgemm_epilogue(const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lc, int lr, int bz,
+                                               const float* __restrict__ bias, const float* R, int ldr, const void* __restrict__ Mk,
+                                               int ldm, float* C, int ldc, uint16_t* __restrict__ C16, int ldc16, int M, int N,
+                                               size_t zs_c) {
+    const bool vec_ok = ((ldc | ldr | ldm | ldc16) & 3) == 0 && (((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0 &&
+                        ((uintptr_t)Mk & (M16 ? 7 : 15)) == 0 && ((uintptr_t)C16 & 7) == 0 && (zs_c & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm + 32 * i + lc;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn + 32 * j + 8 * q + 4 * lr;          // n .. n + 3
+                if (n >= N) continue;
+                const bool vec = vec_ok && n + 3 < N;
+                const int nu = N - n < 4 ? N - n : 4;                       // elements of the group inside the matrix
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (bias) {
+                    if (vec) { const float4 b4 = *(const float4*)(bias + n); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+                    else { for (int u = 0; u < nu; ++u) v[u] += bias[n + u]; }
+                }
+                if (SPLIT) {
+                    float* dst = C + bz * zs_c + (size_t)m * ldc + n;       // this split's own slice (grad_w)
+                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int u = 0; u < nu; ++u) dst[u] = v[u]; }
+                    continue;
+                }
+                if (Mk) {
+                    if (M16) {               // bf16 tape value > 0: sign clear and not zero
+                        const uint16_t* mp = (const uint16_t*)Mk + (size_t)m * ldm + n;
+                        uint16_t b16[4] = {0, 0, 0, 0};
+                        if (vec) { const uint2 w = *(const uint2*)mp; b16[0] = w.x & 0xffffu; b16[1] = w.x >> 16; b16[2] = w.y & 0xffffu; b16[3] = w.y >> 16; }
+                        else { for (int u = 0; u < nu; ++u) b16[u] = mp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (!((b16[u] & 0x8000u) == 0 && (b16[u] & 0x7fffu) != 0)) v[u] = 0.f;
+                    } else {
+                        const float* mp = (const float*)Mk + (size_t)m * ldm + n;
+                        float mk[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (vec) { const float4 w = *(const float4*)mp; mk[0] = w.x; mk[1] = w.y; mk[2] = w.z; mk[3] = w.w; }
+                        else { for (int u = 0; u < nu; ++u) mk[u] = mp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (!(mk[u] > 0.f)) v[u] = 0.f;
+                    }
+                }
+                if (R) {
+                    const float* rp = R + (size_t)m * ldr + n;
+                    if (vec) { const float4 w = *(const float4*)rp; v[0] += w.x; v[1] += w.y; v[2] += w.z; v[3] += w.w; }
+                    else { for (int u = 0; u < nu; ++u) v[u] += rp[u]; }
+                }
+                if (C) {
+                    float* dst = C + (size_t)m * ldc + n;
+                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int u = 0; u < nu; ++u) dst[u] = v[u]; }
+                }
+                if (C16) {
+                    uint16_t* dst = C16 + (size_t)m * ldc16 + n;
+                    const uint2 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+                    if (vec) *(uint2*)dst = w;
+                    else {
+                        const uint16_t h[4] = {(uint16_t)(w.x & 0xffffu), (uint16_t)(w.x >> 16), (uint16_t)(w.y & 0xffffu), (uint16_t)(w.y >> 16)};
+                        for (int u = 0; u < nu; ++u) dst[u] = h[u];
+                    }
+                }
+            }
+    }
+}
+
 template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
 static __global__ void __launch_bounds__(256) k_mgemm_f32(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
@@ -224,8 +330,10 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
     __shared__ float As[2][16][132];
     __shared__ float Bs[2][16][132];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    int bx, by, bz;
+    if (!mgemm_tile<SPLIT>(M, N, Rn, r_per_split, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int rb = SPLIT ? bz * r_per_split : 0;
     const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     f32x16 acc[2][2];
@@ -279,17 +387,18 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
             float(&b)[4] = fb[g & 1];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q], b[2 * q], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q], b[2 * q + 1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q + 1], b[2 * q], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q + 1], b[2 * q + 1], acc[1][1], 0, 0, 0);
+                // (operands swapped: transposed tiles for mgemm_epilogue)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[2 * q], a[2 * q], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[2 * q + 1], a[2 * q], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[2 * q], a[2 * q + 1], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[2 * q + 1], a[2 * q + 1], acc[1][1], 0, 0, 0);
             }
             if (g < 3) {        // keep the next group's reads ahead of this group's MFMAs in the schedule
                 __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
-        if (rowsum && blockIdx.y == 0 && t < 128) {
+        if (rowsum && by == 0 && t < 128) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) rs += As[buf][r][t];
         }
@@ -297,29 +406,9 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
         buf ^= 1;
     }
     const int lr = lane >> 5, lc = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn + 32 * j + lc;
-            if (n >= N) continue;
-            const float bn = bias ? bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
-                if (m >= M) continue;
-                float v = acc[i][j][e] + bn;
-                if (SPLIT) {
-                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
-                } else {
-                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
-                    if (R) v += R[(size_t)m * ldr + n];
-                    C[(size_t)m * ldc + n] = v;
-                }
-            }
-        }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
-        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+    mgemm_epilogue<SPLIT, false>(acc, m0, n0, wm, wn, lc, lr, bz, bias, R, ldr, Mk, ldm, C, ldc, nullptr, 0, M, N, zs_c);
+    if (rowsum && by == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[bz * zs_r + m0 + t] = rs;
         else atomicAdd(rowsum + m0 + t, rs);
     }
 }
@@ -333,14 +422,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_f32(
 // reduction-major are transposed in registers: a thread owns a 4(r) x 4(x) block and writes 4 x 8 bytes.
 // Requirements (else the caller uses k_mgemm_f32): 16-byte aligned operands, leading dimensions % 4 == 0,
 // the reduction extent % 32 == 0 unless SPLIT (whose row tail is zero-filled), x extents % 4 == 0.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    f32x2v f = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2v));
-}
 
 __device__ __forceinline__ float bf16_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
@@ -463,21 +545,8 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // XCD-aware tile order (1-D grid, mgemm_grid below).  Workgroup ids go round the 8 XCDs, each with its own L2: the tiles
-    // that share an operand — the N tiles of one 128-row block of the activations, or all (m, n) tiles of one reduction
-    // split — get consecutive slots on ONE XCD, so the operand is fetched from HBM once instead of once per tile
-    // (measured before: activations re-read 1.8-2.7x, profiles/r03_pmc_train_mem.txt).
-    const int gx = (M + 127) / 128, gy = (N + 127) / 128;
-    int bx, by, bz = 0;
-    {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int G = SPLIT ? gx * gy : gy;
-        const int NG = SPLIT ? (Rn + r_per_split - 1) / r_per_split : gx;
-        const int grp = (slot / G) * 8 + xcd, tg = slot % G;
-        if (grp >= NG) return;
-        if (SPLIT) { bz = grp; bx = tg % gx; by = tg / gx; }
-        else { bx = grp; by = tg; }
-    }
+    int bx, by, bz;
+    if (!mgemm_tile<SPLIT>(M, N, Rn, r_per_split, bx, by, bz)) return;
     const int m0 = bx * 128, n0 = by * 128;
     const int rb = SPLIT ? bz * r_per_split : 0;
     const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
@@ -535,68 +604,7 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
         __syncthreads();
         buf ^= 1;
     }
-    // 16-byte accesses need 16-byte rows: every leading dimension a multiple of 4 elements, every base aligned (N % 4 == 0 is
-    // the launcher's condition already); otherwise element by element
-    const bool vec = ((ldc | ldr | ldm | ldc16) & 3) == 0 && (((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0 &&
-                     ((uintptr_t)Mk & (M16 ? 7 : 15)) == 0 && ((uintptr_t)C16 & 7) == 0 && (zs_c & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm + 32 * i + lc;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn + 32 * j + 8 * q + 4 * lr;          // n .. n + 3 (N % 4 == 0: all four or none)
-                if (n >= N) continue;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (bias) {
-                    if (vec) { const float4 b4 = *(const float4*)(bias + n); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-                    else { for (int u = 0; u < 4; ++u) v[u] += bias[n + u]; }
-                }
-                if (SPLIT) {
-                    float* dst = C + bz * zs_c + (size_t)m * ldc + n;       // this split's own slice (grad_w)
-                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                    else { for (int u = 0; u < 4; ++u) dst[u] = v[u]; }
-                    continue;
-                }
-                if (Mk) {
-                    if (M16) {               // bf16 tape value > 0: sign clear and not zero
-                        const uint16_t* mp = (const uint16_t*)Mk + (size_t)m * ldm + n;
-                        uint16_t b16[4];
-                        if (vec) { const uint2 w = *(const uint2*)mp; b16[0] = w.x & 0xffffu; b16[1] = w.x >> 16; b16[2] = w.y & 0xffffu; b16[3] = w.y >> 16; }
-                        else { for (int u = 0; u < 4; ++u) b16[u] = mp[u]; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (!((b16[u] & 0x8000u) == 0 && (b16[u] & 0x7fffu) != 0)) v[u] = 0.f;
-                    } else {
-                        const float* mp = (const float*)Mk + (size_t)m * ldm + n;
-                        float mk[4];
-                        if (vec) { const float4 w = *(const float4*)mp; mk[0] = w.x; mk[1] = w.y; mk[2] = w.z; mk[3] = w.w; }
-                        else { for (int u = 0; u < 4; ++u) mk[u] = mp[u]; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (!(mk[u] > 0.f)) v[u] = 0.f;
-                    }
-                }
-                if (R) {
-                    const float* rp = R + (size_t)m * ldr + n;
-                    if (vec) { const float4 w = *(const float4*)rp; v[0] += w.x; v[1] += w.y; v[2] += w.z; v[3] += w.w; }
-                    else { for (int u = 0; u < 4; ++u) v[u] += rp[u]; }
-                }
-                if (C) {
-                    float* dst = C + (size_t)m * ldc + n;
-                    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                    else { for (int u = 0; u < 4; ++u) dst[u] = v[u]; }
-                }
-                if (C16) {
-                    uint16_t* dst = C16 + (size_t)m * ldc16 + n;
-                    const uint2 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
-                    if (vec) *(uint2*)dst = w;
-                    else { dst[0] = w.x & 0xffffu; dst[1] = w.x >> 16; dst[2] = w.y & 0xffffu; dst[3] = w.y >> 16; }
-                }
-            }
-    }
+    mgemm_epilogue<SPLIT, M16>(acc, m0, n0, wm, wn, lc, lr, bz, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, zs_c);
     if (rowsum && by == 0 && t < 128 && m0 + t < M) {
         if (SPLIT) rowsum[bz * zs_r + m0 + t] = rs;
         else atomicAdd(rowsum + m0 + t, rs);
@@ -615,8 +623,10 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
     __shared__ __attribute__((aligned(16))) uint16_t As[2][128][40];      // [hi, lo]
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][128][40];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int rb = SPLIT ? blockIdx.z * r_per_split : 0;
+    int bx, by, bz;
+    if (!mgemm_tile<SPLIT>(M, N, Rn, r_per_split, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int rb = SPLIT ? bz * r_per_split : 0;
     const int re = SPLIT ? min(Rn, rb + r_per_split) : Rn;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     const int lr = lane >> 5, lc = lane & 31;
@@ -646,17 +656,18 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
             bf16x8 a1h = *(const bf16x8*)&As[0][wm + 32 + lc][ko], a1l = *(const bf16x8*)&As[1][wm + 32 + lc][ko];
             bf16x8 b0h = *(const bf16x8*)&Bs[0][wn + lc][ko], b0l = *(const bf16x8*)&Bs[1][wn + lc][ko];
             bf16x8 b1h = *(const bf16x8*)&Bs[0][wn + 32 + lc][ko], b1l = *(const bf16x8*)&Bs[1][wn + 32 + lc][ko];
+            // (operands swapped: transposed tiles for mgemm_epilogue)
 #define PNR_X3(ACC, AH, AL, BH, BL)                                              \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0)
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BH, AL, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BL, AH, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BH, AH, ACC, 0, 0, 0)
             PNR_X3(acc[0][0], a0h, a0l, b0h, b0l);
             PNR_X3(acc[0][1], a0h, a0l, b1h, b1l);
             PNR_X3(acc[1][0], a1h, a1l, b0h, b0l);
             PNR_X3(acc[1][1], a1h, a1l, b1h, b1l);
 #undef PNR_X3
         }
-        if (rowsum && blockIdx.y == 0 && t < 128) {
+        if (rowsum && by == 0 && t < 128) {
 #pragma unroll
             for (int r = 0; r < 32; r += 2) {
                 uint32_t ph = *(const uint32_t*)&As[0][t][r], pl = *(const uint32_t*)&As[1][t][r];
@@ -666,29 +677,9 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn + 32 * j + lc;
-            if (n >= N) continue;
-            const float bn = bias ? bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * lr + (e & 3);
-                if (m >= M) continue;
-                float v = acc[i][j][e] + bn;
-                if (SPLIT) {
-                    C[blockIdx.z * zs_c + (size_t)m * ldc + n] = v;        // this split's own slice (grad_w)
-                } else {
-                    if (Mk && !(Mk[(size_t)m * ldm + n] > 0.f)) v = 0.f;
-                    if (R) v += R[(size_t)m * ldr + n];
-                    C[(size_t)m * ldc + n] = v;
-                }
-            }
-        }
-    if (rowsum && blockIdx.y == 0 && t < 128 && m0 + t < M) {
-        if (SPLIT) rowsum[blockIdx.z * zs_r + m0 + t] = rs;
+    mgemm_epilogue<SPLIT, false>(acc, m0, n0, wm, wn, lc, lr, bz, bias, R, ldr, Mk, ldm, C, ldc, nullptr, 0, M, N, zs_c);
+    if (rowsum && by == 0 && t < 128 && m0 + t < M) {
+        if (SPLIT) rowsum[bz * zs_r + m0 + t] = rs;
         else atomicAdd(rowsum + m0 + t, rs);
     }
 }
@@ -1115,9 +1106,6 @@ static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0
 // instead of Mk), Y16 (a bf16 copy of the result; Y may then be NULL).  Only the bf16 MFMA kernel takes them.
 struct G16 { const uint16_t* X16; const uint16_t* Mk16; uint16_t* Y16; };
 
-// 1-D grid of k_mgemm_bf16 (its XCD-aware tile order): n_groups rounded up to the 8 XCDs, `group` tiles each
-static inline dim3 mgemm_grid(int64_t n_groups, int group) { return dim3((unsigned)(((n_groups + 7) / 8) * 8 * group)); }
-
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
                       const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s) {
@@ -1144,18 +1132,18 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
                     const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, int half = 0) {
     if (M == 0) return PNR_OK;
     if (half && N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(X, ldx) && al16(W, ldw)) {
-        dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+        const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
         if (half == 3)
             hipLaunchKernelGGL((k_mgemm_bf16x3<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
                                ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
         else
-            hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), mgemm_grid((M + 127) / 128, (N + 127) / 128),
-                               dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+            hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
+                               ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
     if (N >= 32 && K >= 16) {       // MFMA tile kernel; the skinny heads (N = 4, K = 4) stay on the FMA kernel
-        dim3 grid((unsigned)((M + 127) / 128), (N + 127) / 128);
+        const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
         hipLaunchKernelGGL((k_mgemm_f32<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
                            Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0, vec_flags(X, ldx, W, ldw));
         PNR_LAUNCH_CHECK();
@@ -1252,19 +1240,17 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     float* pbk = db ? pb : nullptr;
     if (mfma_shape) {
         // dW = A B with A(n, r = m) = dY[m][n] and B(r = m, k) = act(X[m][k]): both stored reduction-major
-        dim3 grid((N + 127) / 128, (K + 127) / 128, (unsigned)nz);
+        const dim3 grid = mgemm_grid(nz, ((N + 127) / 128) * ((K + 127) / 128));
         if (use_half && half == 3)
             hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half && X16)
-            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>),
-                               mgemm_grid(nz, ((N + 127) / 128) * ((K + 127) / 128)), dim3(256), 0, s,
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>), grid, dim3(256), 0, s,
                                (const void*)dY, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
                                (const void*)nullptr, 0, pw, K, pbk, N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half)
-            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>),
-                               mgemm_grid(nz, ((N + 127) / 128) * ((K + 127) / 128)), dim3(256), 0, s, dY, ldy, X, ldx,
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
         else
