@@ -216,6 +216,46 @@ __device__ __forceinline__ void mg_stage(float (*T)[132], float (&v)[8]) {
     }
 }
 
+// The output head: Y[M,4] = act(X[M,K]) W[4,K]^T + b — 4 output columns make a tile GEMM mostly padding (the 64 x 64 FMA kernel
+// ran it at 0.65 TB/s of X).  One wave per row: lanes read the row as float4 (coalesced), keep their slice of W in registers,
+// and the four dot products are summed over the wave; 4 rows in flight per wave.  HBM-bound: 4 K bytes per row.
+template <bool RELU_X, int KQ /* K / 256 */>
+static __global__ void __launch_bounds__(256) k_linear_head(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ b, float* __restrict__ Y, int ldy, int M) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    float4 w[4][KQ];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) w[n][q] = *(const float4*)(W + (size_t)n * ldw + 256 * q + 4 * lane);
+    const float b0 = b ? b[0] : 0.f, b1 = b ? b[1] : 0.f, b2 = b ? b[2] : 0.f, b3 = b ? b[3] : 0.f;
+    for (int m0 = wave * 4; m0 < M; m0 += n_waves * 4) {
+        float4 x[4][KQ];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + r < M ? m0 + r : M - 1;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) x[r][q] = *(const float4*)(X + (size_t)m * ldx + 256 * q + 4 * lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                float4 v = x[r][q];
+                if (RELU_X) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[n] = fmaf(v.w, w[n][q].w, fmaf(v.z, w[n][q].z, fmaf(v.y, w[n][q].y, fmaf(v.x, w[n][q].x, acc[n]))));
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = wave_sum_dpp(acc[n]);
+            if (lane == 0 && m0 + r < M) *(float4*)(Y + (size_t)(m0 + r) * ldy) = make_float4(acc[0] + b0, acc[1] + b1, acc[2] + b2, acc[3] + b3);
+        }
+    }
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -1146,6 +1186,17 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
         const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
         hipLaunchKernelGGL((k_mgemm_f32<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr,
                            Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0, vec_flags(X, ldx, W, ldw));
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
+    if (!TRANS_W && N == 4 && !R && !Mk && (K == 256 || K == 512) && al16(X, ldx) && al16(W, ldw) && al16(Y, ldy)) {
+        // the output head (lin_out, d_out = 4)
+        int64_t blocks = (M + 15) / 16;
+        if (blocks > 2048) blocks = 2048;
+        if (K == 512)
+            hipLaunchKernelGGL((k_linear_head<RELU_X, 2>), dim3((unsigned)blocks), dim3(256), 0, s, X, ldx, W, ldw, b, Y, ldy, (int)M);
+        else
+            hipLaunchKernelGGL((k_linear_head<RELU_X, 1>), dim3((unsigned)blocks), dim3(256), 0, s, X, ldx, W, ldw, b, Y, ldy, (int)M);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
