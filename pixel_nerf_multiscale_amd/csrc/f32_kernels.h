@@ -7,49 +7,62 @@ namespace pnr {
 
 // zx[col][0..L) = bilinear latent sample, zx[col][L..L+d_in) = pos-enc(x_rot) ++ R*viewdir
 // col = v*CH + pl for point g0+pl of the chunk and source view v (view index obj*NS+v).
-static __global__ void k_features_f32(pnr_views vw, PointSrc src, int64_t g0, int CH, int64_t pts_per_obj,
+// One wave per (view, point) column: the geometry (point, camera, rotation, projection, the four taps of every level) is formed
+// once per wave — the element-per-thread form redid it (and a 64-bit div / mod) for each of the ~300 row elements — and the lanes
+// walk the row, 64 consecutive elements per step (coalesced stores).  Same arithmetic per element: bit-identical rows.
+static __global__ void __launch_bounds__(256) k_features_f32(pnr_views vw, PointSrc src, int64_t g0, int CH, int64_t pts_per_obj,
                                int L, int d_in, int use_code_viewdirs, int num_freqs, float freq_factor,
                                float* __restrict__ zx, int ldz /* row stride of zx, >= L + d_in */) {
     const int E = L + d_in;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)CH * vw.n_views * E;
-    if (idx >= total) return;
-    int e = (int)(idx % E);
-    int64_t col = idx / E;
-    int v = (int)(col / CH);
-    int pl = (int)(col % CH);
-    int64_t g = g0 + pl;
-    int obj = (int)(g / pts_per_obj);
-    int view = obj * vw.n_views + v;
-    float p[3], d[3], xr[3];
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= (int64_t)CH * vw.n_views) return;
+    const int v = (int)(col / CH);
+    const int pl = (int)(col - (int64_t)v * CH);
+    const int64_t g = g0 + pl;
+    const int obj = (int)(g / pts_per_obj);
+    const int view = obj * vw.n_views + v;
+    float p[3], d[3], xr[3], dr[3];
     fetch_point(src, g, p, d);
-    Cam cam = load_cam(vw, view);
+    const Cam cam = load_cam(vw, view);
     rot3(cam.R, p, xr);
-    float val;
-    if (e < L) {
-        float u, w;
-        project(cam, xr, u, w);
-        int lvl = 0, ch = e;
-        while (ch >= vw.lat_c[lvl]) { ch -= vw.lat_c[lvl]; ++lvl; }
-        int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
-        Taps t = bilinear_taps(u, w, W, H);
-        const float* base = vw.latent[lvl] + ((size_t)view * C + ch) * (size_t)(H * W);
-        val = 0.f;
+    rot3(cam.R, d, dr);
+    float u, w;
+    project(cam, xr, u, w);
+    float* row = zx + (size_t)col * ldz;
+    // latent part, level by level (the taps are per level)
+    int e0 = 0;
+    for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
+        const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
+        const Taps t = bilinear_taps(u, w, W, H);
+        const float* base = vw.latent[lvl] + (size_t)view * C * (size_t)(H * W);
+        for (int ch = lane; ch < C; ch += 64) {
+            const float* bc = base + (size_t)ch * (size_t)(H * W);
+            float val = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) val += base[t.off[i]] * t.w[i];
-    } else {
-        int j = e - L;
-        float dr[3];
-        rot3(cam.R, d, dr);
-        if (use_code_viewdirs) {
-            float x6[6] = {xr[0], xr[1], xr[2], dr[0], dr[1], dr[2]};
-            val = posenc_elem(x6, 6, j, freq_factor);
-        } else {
-            int dcode = 3 + 6 * num_freqs;
-            val = (j < dcode) ? posenc_elem(xr, 3, j, freq_factor) : dr[j - dcode];
+            for (int i = 0; i < 4; ++i) val += bc[t.off[i]] * t.w[i];
+            row[e0 + ch] = val;
         }
+        e0 += C;
     }
-    zx[(size_t)col * ldz + e] = val;
+    // code part
+    const float x6[6] = {xr[0], xr[1], xr[2], dr[0], dr[1], dr[2]};
+    const int dcode = 3 + 6 * num_freqs;
+    for (int j = lane; j < E - L; j += 64) {
+        float val;
+        if (use_code_viewdirs) val = posenc_elem(x6, 6, j, freq_factor);
+        else val = (j < dcode) ? posenc_elem(xr, 3, j, freq_factor) : dr[j - dcode];
+        row[L + j] = val;
+    }
+}
+
+// launch: 4 columns (waves) per block
+static inline void features_launch(const pnr_views& vw, const PointSrc& src, int64_t g0, int CH, int64_t pts_per_obj, int L, int d_in,
+                                   int use_code_viewdirs, int num_freqs, float freq_factor, float* zx, int ldz, hipStream_t s) {
+    const int64_t cols = (int64_t)CH * vw.n_views;
+    if (cols == 0) return;
+    hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, vw, src, g0, CH, pts_per_obj, L, d_in,
+                       use_code_viewdirs, num_freqs, freq_factor, zx, ldz);
 }
 
 // x (NS, CH, H) -> (CH, H): mean or max over the view axis (util.combine_interleaved, util.py:466-476)

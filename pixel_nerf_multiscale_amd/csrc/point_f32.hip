@@ -60,9 +60,7 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* o4 = h + (size_t)F32_CHUNK * NS * H;
     for (int64_t g0 = 0; g0 < n_points; g0 += F32_CHUNK) {
         int CH = (int)((n_points - g0 < F32_CHUNK) ? (n_points - g0) : F32_CHUNK);
-        int64_t tot = (int64_t)CH * NS * E;
-        hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, g0, CH,
-                           pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E);
+        features_launch(*vw, src, g0, CH, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E, s);
         PNR_LAUNCH_CHECK();
         int32_t rc;
         if ((rc = chain_f32(mlp, zx, E, CH, NS, x, h, o4, s))) return rc;

@@ -1338,9 +1338,7 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
-    int64_t tot = MV * (L + Din);
-    hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
-                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
+    features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s);
     PNR_LAUNCH_CHECK();
     auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
         hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
@@ -1411,9 +1409,7 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
     // GEMM products: 0 = fp32 MFMA, 1 = bf16 MFMA, 3 = bf16x3 split (fp32-class) — all on the fp32 tape
     const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
-    int64_t tot = MV * (L + Din);
-    hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, *vw, src, (int64_t)0,
-                       (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E);
+    features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s);
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
