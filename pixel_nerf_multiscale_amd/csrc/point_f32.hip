@@ -16,7 +16,10 @@ static int32_t linear(const float* X, int ldx, const float* W, const float* b, f
     return linear_f32_mfma(X, ldx, W, K, b, RELU_IN, ACCUM, Y, ldy, M, N, K, s);
 }
 
-static const int F32_CHUNK = 16384;   // points per chunk
+// points per chunk: 49152 x NS rows = 384 x NS row tiles x 4 column tiles per GEMM launch — two full rounds of the 768 workgroup
+// slots (3 per CU).  With 16384 a launch was 512 workgroups, 2 per CU and nothing behind them: 0.57 of the fp32 MFMA peak
+// against 0.64 (24576: 0.62; 98304 / 196608: 0.64 / 0.65).  Workspace: ~5.3 KB per point and view.
+static const int F32_CHUNK = 49152;
 
 uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
     uint64_t per_pt = (uint64_t)vw->n_views * (((mlp->d_latent + mlp->d_in + 3) & ~3) + 2ull * mlp->d_hidden) + 4;
