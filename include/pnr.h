@@ -311,6 +311,14 @@ int32_t pnr_event_record(void* ev, void* stream);
 int32_t pnr_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int32_t pnr_event_destroy(void* ev);
 
+/* Diagnostics of the tile GEMMs behind the fp32 path and the training path (host functions, no device work): size of their
+ * 1-D launch grid, and the tile a workgroup id maps to — (m tile, n tile, reduction split) in out3, return 1, or 0 for a
+ * padding workgroup of the rounded-up grid.  The order is XCD-aware: workgroup ids go round the 8 XCDs, and the tiles that
+ * share an operand take consecutive slots of ONE XCD (tests/test_host_cpu.py checks the bijection and that property). */
+int64_t pnr_debug_gemm_grid(int32_t M, int32_t N, int32_t Rn, int32_t rows_per_split, int32_t split);
+int32_t pnr_debug_gemm_tile(int32_t block, int32_t M, int32_t N, int32_t Rn, int32_t rows_per_split, int32_t split,
+                            int32_t* out3);
+
 #ifdef __cplusplus
 }
 #endif

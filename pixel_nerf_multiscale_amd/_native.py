@@ -114,6 +114,8 @@ PROTOTYPES = {
     "pnr_event_record": (_i32, [_fp, _fp]),
     "pnr_event_elapsed_ms": (_i32, [_fp, _fp, C.POINTER(C.c_float)]),
     "pnr_event_destroy": (_i32, [_fp]),
+    "pnr_debug_gemm_grid": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
+    "pnr_debug_gemm_tile": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int32)]),
 }
 
 

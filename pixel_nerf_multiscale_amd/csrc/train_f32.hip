@@ -272,17 +272,21 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 static inline dim3 mgemm_grid(int64_t n_groups, int group) { return dim3((unsigned)(((n_groups + 7) / 8) * 8 * group)); }
 
 template <bool SPLIT>
-__device__ __forceinline__ bool mgemm_tile(int M, int N, int Rn, int r_per_split, int& bx, int& by, int& bz) {
+__host__ __device__ __forceinline__ bool mgemm_tile_of(int block, int M, int N, int Rn, int r_per_split, int& bx, int& by, int& bz) {
     const int gx = (M + 127) / 128, gy = (N + 127) / 128;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = block & 7, slot = block >> 3;
     const int G = SPLIT ? gx * gy : gy;
     const int NG = SPLIT ? (Rn + r_per_split - 1) / r_per_split : gx;
     const int grp = (slot / G) * 8 + xcd, tg = slot % G;
     bx = by = bz = 0;
-    if (grp >= NG) return false;
+    if (grp >= NG) return false;        // padding block of the rounded-up grid
     if (SPLIT) { bz = grp; bx = tg % gx; by = tg / gx; }
     else { bx = grp; by = tg; }
     return true;
+}
+template <bool SPLIT>
+__device__ __forceinline__ bool mgemm_tile(int M, int N, int Rn, int r_per_split, int& bx, int& by, int& bz) {
+    return mgemm_tile_of<SPLIT>((int)blockIdx.x, M, N, Rn, r_per_split, bx, by, bz);
 }
 
 // Epilogue of a 128 x 128 workgroup tile whose MFMAs ran with the operands SWAPPED (mfma(b, a)): the 32 x 32 tiles come out
@@ -1534,6 +1538,21 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
 }  // namespace pnr
 
 using namespace pnr;
+
+// Host-side view of the tile GEMMs' grid (tests: every tile exactly once, the tiles that share an operand on one XCD).
+extern "C" int64_t pnr_debug_gemm_grid(int32_t M, int32_t N, int32_t Rn, int32_t rows_per_split, int32_t split) {
+    const int64_t gx = (M + 127) / 128, gy = (N + 127) / 128;
+    if (split) return mgemm_grid(((int64_t)Rn + rows_per_split - 1) / rows_per_split, (int)(gx * gy)).x;
+    return mgemm_grid(gx, (int)gy).x;
+}
+extern "C" int32_t pnr_debug_gemm_tile(int32_t block, int32_t M, int32_t N, int32_t Rn, int32_t rows_per_split, int32_t split,
+                                       int32_t* out3) {
+    int bx, by, bz;
+    const bool ok = split ? mgemm_tile_of<true>(block, M, N, Rn, rows_per_split, bx, by, bz)
+                          : mgemm_tile_of<false>(block, M, N, Rn, rows_per_split, bx, by, bz);
+    out3[0] = bx; out3[1] = by; out3[2] = bz;
+    return ok ? 1 : 0;
+}
 
 extern "C" int32_t pnr_composite_bwd(const float* rays, const float* z, const float* rgbsigma, int64_t n_rays,
                                      int32_t K, int32_t white_bkgd, const float* d_weights, const float* d_rgb,

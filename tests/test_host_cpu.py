@@ -201,3 +201,31 @@ def test_gen_rays_mirror_matches_reference_fixture():
                              cs["z_far"], c=c)
         assert rays.shape == cs["rays"].shape
         assert np.abs(rays.numpy() - cs["rays"]).max() <= 2e-6, cs["name"]
+
+
+@pytest.mark.parametrize("M,N,Rn,rows,split", [(49152, 512, 512, 0, 0), (32768, 512, 512, 0, 0), (300, 42, 512, 0, 0), (129, 512, 64, 0, 0),
+                                               (512, 512, 40960, 1024, 1), (512, 42, 3000, 1024, 1), (4, 512, 100, 64, 1)])
+def test_tile_gemm_grid_is_a_bijection_and_xcd_local(M, N, Rn, rows, split):
+    """The 1-D, XCD-aware launch grid of the tile GEMMs (fp32 path + training path; csrc/train_f32.hip mgemm_grid /
+    mgemm_tile_of), through its host-side diagnostics: every (m tile, n tile[, split]) is visited exactly once, padding
+    workgroups are the rest, and the tiles that share an operand — the n tiles of one m tile, or all tiles of one split —
+    sit on ONE XCD (workgroup id mod 8) in consecutive slots."""
+    import ctypes as C
+    from pixel_nerf_multiscale_amd import _native as N_
+    grid = N_.lib.pnr_debug_gemm_grid(M, N, Rn, rows, split)
+    gx, gy = (M + 127) // 128, (N + 127) // 128
+    gz = (Rn + rows - 1) // rows if split else 1
+    assert grid % 8 == 0 and grid >= gx * gy * gz
+    out = (C.c_int32 * 3)()
+    seen, by_group = {}, {}
+    for b in range(grid):
+        if N_.lib.pnr_debug_gemm_tile(b, M, N, Rn, rows, split, out):
+            tile = (out[0], out[1], out[2])
+            assert tile not in seen and 0 <= tile[0] < gx and 0 <= tile[1] < gy and 0 <= tile[2] < gz
+            seen[tile] = b
+            by_group.setdefault(tile[2] if split else tile[0], []).append(b)
+    assert len(seen) == gx * gy * gz
+    for grp, blocks in by_group.items():
+        assert len({b % 8 for b in blocks}) == 1                                   # one XCD
+        slots = sorted(b // 8 for b in blocks)
+        assert slots == list(range(slots[0], slots[0] + len(slots)))              # consecutive slots of that XCD
