@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PNR_VERSION 101          /* 0.1.1: output strides, per-object ray index stride */
+#define PNR_VERSION 102          /* 0.1.2: pnr_views.uv_scale_{x,y} (opt-in upstream texel mapping); 101: output strides, per-object ray index stride */
 #define PNR_MAX_LEVELS 5         /* encoder levels of a multi-scale latent (encoder.py:62-73) */
 #define PNR_MAX_BLOCKS 8         /* ResnetFC blocks (resnetfc.py:147) */
 
@@ -90,6 +90,14 @@ typedef struct pnr_views {
     const void* latent_packed[PNR_MAX_LEVELS];
     int32_t packed_dtype;
     int32_t reserved1;
+    /* Texel coordinate of an image point on level i = uv * uv_scale_{x,y}[i].  0 (the default of a zeroed struct) = 1.0 =
+     * the reference fork's mapping: encoder.py:152-164 normalises uv by the LATENT size and ignores image_size, so the
+     * texel coordinate equals the image-pixel coordinate — the parity target.  Opt-in: upstream pixelNeRF's
+     * mapping (uv * latent_scaling / image_size, align_corners) = W_i / W_image, H_i / H_image per level — what a
+     * checkpoint trained with upstream semantics expects (SpatialEncoder.uv_scale = "image"; parity unpinned: the
+     * reference holds no fixture for it).  The gradient of the lookup w.r.t. uv carries the same factor. */
+    float uv_scale_x[PNR_MAX_LEVELS];
+    float uv_scale_y[PNR_MAX_LEVELS];
 } pnr_views;
 
 /* NeRFRenderer attributes (render/nerf.py:62-96) + the PixelNeRFNet switches the kernels need. */

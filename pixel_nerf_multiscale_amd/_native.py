@@ -42,6 +42,7 @@ class pnr_views(C.Structure):
         ("latent", _fp * PNR_MAX_LEVELS),
         ("lat_c", C.c_int32 * PNR_MAX_LEVELS), ("lat_h", C.c_int32 * PNR_MAX_LEVELS), ("lat_w", C.c_int32 * PNR_MAX_LEVELS),
         ("latent_packed", _fp * PNR_MAX_LEVELS), ("packed_dtype", C.c_int32), ("reserved1", C.c_int32),
+        ("uv_scale_x", C.c_float * PNR_MAX_LEVELS), ("uv_scale_y", C.c_float * PNR_MAX_LEVELS),
     ]
 
 

@@ -34,7 +34,7 @@ static __global__ void __launch_bounds__(256) k_features_f32(pnr_views vw, Point
     int e0 = 0;
     for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
         const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
-        const Taps t = bilinear_taps(u, w, W, H);
+        const Taps t = bilinear_taps(u * uv_sx(vw, lvl), w * uv_sy(vw, lvl), W, H);
         const float* base = vw.latent[lvl] + (size_t)view * C * (size_t)(H * W);
         for (int ch = lane; ch < C; ch += 64) {
             const float* bc = base + (size_t)ch * (size_t)(H * W);
@@ -57,12 +57,21 @@ static __global__ void __launch_bounds__(256) k_features_f32(pnr_views vw, Point
 }
 
 // launch: 4 columns (waves) per block
-static inline void features_launch(const pnr_views& vw, const PointSrc& src, int64_t g0, int CH, int64_t pts_per_obj, int L, int d_in,
-                                   int use_code_viewdirs, int num_freqs, float freq_factor, float* zx, int ldz, hipStream_t s) {
+// The kernel writes sum(lat_c) latent columns per row whatever L says: the MLP's d_latent must BE that sum (an MLP without a
+// latent input, or coarse / fine MLPs of different d_latent, against encoded maps would overrun into the code columns).
+static inline bool latent_width_matches(const pnr_views& vw, int L) {
+    int sum = 0;
+    for (int i = 0; i < vw.n_levels; ++i) sum += vw.lat_c[i];
+    return sum == L;
+}
+static inline int32_t features_launch(const pnr_views& vw, const PointSrc& src, int64_t g0, int CH, int64_t pts_per_obj, int L, int d_in,
+                                      int use_code_viewdirs, int num_freqs, float freq_factor, float* zx, int ldz, hipStream_t s) {
+    if (!latent_width_matches(vw, L)) return PNR_E_SHAPE;
     const int64_t cols = (int64_t)CH * vw.n_views;
-    if (cols == 0) return;
+    if (cols == 0) return PNR_OK;
     hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, vw, src, g0, CH, pts_per_obj, L, d_in,
                        use_code_viewdirs, num_freqs, freq_factor, zx, ldz);
+    return PNR_OK;
 }
 
 // x (NS, CH, H) -> (CH, H): mean or max over the view axis (util.combine_interleaved, util.py:466-476)

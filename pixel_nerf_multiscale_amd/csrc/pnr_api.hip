@@ -307,6 +307,7 @@ static int32_t render_impl(const pnr_params* params, const pnr_mlp* coarse, cons
         job.on = 1; job.K = Kc; job.gen_z = 1; job.lindisp = params->lindisp; job.white_bkgd = params->white_bkgd;
         job.n_rays = n_rays; job.noise_c = nz.noise_c; job.seed = seed; job.key = key;
         job.z_out = zc; job.rgb_out = rgb_c; job.depth_out = dep_c;
+        job.z_needed = (Kf > 0 || outputs->z_coarse) ? 1 : 0;        // the resampling / the caller read the coarse positions
         job.rgb_stride = s_rgb_c; job.depth_stride = s_dep_c; job.w_stride = s_w_c;
         job.w_out = (Kf > 0 || outputs->coarse_weights) ? w_c : nullptr;      // only the resampling and the caller read them
         if (cam) { job.from_cam = 1; job.cam = *cam; job.pix0 = (int)pix0; }

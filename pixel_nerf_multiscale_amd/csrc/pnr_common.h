@@ -18,6 +18,7 @@
         hipError_t _e = hipGetLastError();          \
         if (_e != hipSuccess) return (int32_t)_e;   \
     } while (0)
+#define PNR_TRY(expr) do { int32_t _rc = (expr); if (_rc) return _rc; } while (0)
 
 namespace pnr {
 
@@ -184,6 +185,11 @@ __device__ __forceinline__ void project(const Cam& c, const float* xrot, float& 
 // floor.  Returns the 4 tap offsets (y*W+x, clamped in-bounds) and weights (0 for out-of-bounds taps).
 struct Taps { int off[4]; float w[4]; };
 
+// pnr_views.uv_scale_{x,y}[lvl]: 0 = 1.0 = the fork's mapping (texel coordinate = image-pixel coordinate); a
+// product with exactly 1.0f returns its operand bit for bit (NaN and inf included), so the default stays the parity path.
+__device__ __forceinline__ float uv_sx(const pnr_views& vw, int lvl) { const float s = vw.uv_scale_x[lvl]; return s != 0.f ? s : 1.0f; }
+__device__ __forceinline__ float uv_sy(const pnr_views& vw, int lvl) { const float s = vw.uv_scale_y[lvl]; return s != 0.f ? s : 1.0f; }
+
 __device__ __forceinline__ Taps bilinear_taps(float u, float v, int W, int H) {
     float gx = (u / (float)(W - 1)) * 2.0f - 1.0f;
     float gy = (v / (float)(H - 1)) * 2.0f - 1.0f;
@@ -293,25 +299,26 @@ template <bool NT> __device__ __forceinline__ float4 ld_f4(const float4* p) {
 // composite (nerf.py:178-182,223-249), one WAVE per ray: alpha = 1-exp(-delta*relu(sigma)); T = exclusive
 // cumprod(1-alpha+1e-10); w = alpha*T; rgb = sum w c (+ 1 - sum w if white background); depth = sum w z.  The transmittance
 // product is a wave-wide multiplicative scan per 64-sample segment with a carry.  Returns (rgb, depth) in lane 0.
-template <bool NT>
-__device__ __forceinline__ float4 composite_ray(const float* zr, const float4* cr, int K, float far, int white_bkgd,
-                                                float* wr /* or null */, int lane) {
+// LZ(k) -> z_k, LC(k) -> (r, g, b, sigma)_k of this ray: global memory (stage kernel, the fused launch's memory route) or the
+// workgroup's LDS ring (the fused launch's on-chip route) — ONE body, so every route is the same arithmetic in the same order.
+template <typename LZ, typename LC>
+__device__ __forceinline__ float4 composite_ray_t(LZ lz, LC lc, int K, float far, int white_bkgd, float* wr /* or null */, int lane) {
     float carry = 1.0f;
     float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, aw = 0.f;
     // the next 64-sample segment's loads are issued before this segment's scan (same arithmetic, one round trip hidden)
     // z_{k+1} is the neighbouring lane's z_k (one DPP wave shift, no second load); lane 63's neighbour is lane 0 of the next segment
     int k = lane;
     bool act = k < K;
-    float zk = act ? ld_f<NT>(zr + k) : 0.f;
-    float4 c = act ? ld_f4<NT>(cr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float zk = act ? lz(k) : 0.f;
+    float4 c = act ? lc(k) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k2 = k0 + 64 + lane;
         const bool act2 = k2 < K;
         float zk2 = 0.f;
         float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k0 + 64 < K) {
-            zk2 = act2 ? ld_f<NT>(zr + k2) : 0.f;
-            c2 = act2 ? ld_f4<NT>(cr + k2) : make_float4(0.f, 0.f, 0.f, 0.f);
+            zk2 = act2 ? lz(k2) : 0.f;
+            c2 = act2 ? lc(k2) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float zn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zk), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
         const float z_next_seg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zk2), 0));
@@ -332,6 +339,11 @@ __device__ __forceinline__ float4 composite_ray(const float* zr, const float4* c
     aw = wave_sum_dpp(aw);
     if (white_bkgd) { float bg = 1.0f - aw; ar = ar + bg; ag = ag + bg; ab = ab + bg; }
     return make_float4(ar, ag, ab, ad);
+}
+template <bool NT>
+__device__ __forceinline__ float4 composite_ray(const float* zr, const float4* cr, int K, float far, int white_bkgd,
+                                                float* wr /* or null */, int lane) {
+    return composite_ray_t([zr](int k) { return ld_f<NT>(zr + k); }, [cr](int k) { return ld_f4<NT>(cr + k); }, K, far, white_bkgd, wr, lane);
 }
 
 // sample_fine + sample_fine_depth + cat + sort (nerf.py:120-161,285-295), one WAVE per ray with wave-private LDS scratch
@@ -407,6 +419,10 @@ struct RayJob {
     int lindisp, white_bkgd;
     int from_cam;                   // 1: ray r is pixel pix0 + r of `cam` (no ray tensor)
     int rays_per_wg;
+    // cmp_lds (set by point_mfma): a finished ray is composited from the workgroup's LDS ring — the tile epilogue leaves the
+    // point's (rgb, sigma) and z there instead of in global memory (K <= CMP_MAX_K, ring of CMP_RING points).  z_needed: the
+    // coarse positions are also wanted in z_out (a fine pass or the caller reads them); without cmp_lds z_out is always written.
+    int cmp_lds, z_needed;
     int64_t n_rays;
     const float* noise_c; uint64_t seed; RayKey key;
     float* z_out; float* w_out; float* rgb_out; float* depth_out;      // w_out may be NULL

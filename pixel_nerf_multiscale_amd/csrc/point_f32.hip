@@ -63,7 +63,7 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* o4 = h + (size_t)F32_CHUNK * NS * H;
     for (int64_t g0 = 0; g0 < n_points; g0 += F32_CHUNK) {
         int CH = (int)((n_points - g0 < F32_CHUNK) ? (n_points - g0) : F32_CHUNK);
-        features_launch(*vw, src, g0, CH, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E, s);
+        PNR_TRY(features_launch(*vw, src, g0, CH, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E, s));
         PNR_LAUNCH_CHECK();
         int32_t rc;
         if ((rc = chain_f32(mlp, zx, E, CH, NS, x, h, o4, s))) return rc;
@@ -115,7 +115,7 @@ static __global__ void k_index_latent(pnr_views vw, const float* __restrict__ uv
     int lvl = 0, ch = e;
     while (ch >= vw.lat_c[lvl]) { ch -= vw.lat_c[lvl]; ++lvl; }
     const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
-    const Taps t = bilinear_taps(q[0], q[1], W, H);
+    const Taps t = bilinear_taps(q[0] * uv_sx(vw, lvl), q[1] * uv_sy(vw, lvl), W, H);
     const float* base = vw.latent[lvl] + ((size_t)view * C + ch) * (size_t)(H * W);
     float val = 0.f;
 #pragma unroll

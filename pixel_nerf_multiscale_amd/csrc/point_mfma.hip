@@ -49,6 +49,13 @@ static constexpr int LDS_Z = RING_SLOTS * STAGE_BYTES;
 static constexpr int LDS_PTS = LDS_Z + 4 * ZBUF_BYTES;
 static constexpr int LDS_UV = LDS_PTS + 4 * 2 * PTS_BYTES;      // per wave: 64 lanes x (u, v) of the lane's two points
 static constexpr int LDS_BTAB = LDS_UV + 4 * 1024;
+// behind the bias table (when it fits, RayJob.cmp_lds): the compositing ring — (rgb, sigma) and z of the workgroup's last
+// CMP_RING points, written by the tile epilogue, read by the wave that composites a finished ray.  A ray of K <= CMP_MAX_K
+// samples that ends in tile t starts after the end of tile t - 2, and is composited before tile t + 1's epilogue writes
+// again: two tiles of slots are enough.
+static constexpr int CMP_RING = 2 * TILE_PTS, CMP_MAX_K = TILE_PTS;
+static constexpr int CMP_BYTES = CMP_RING * (16 + 4);
+static constexpr int LDS_LIMIT = 160 * 1024;
 
 // ---------------------------------------------------------------------------- 16-bit helpers
 template <int DT> struct Num;
@@ -256,6 +263,14 @@ __global__ void k_pack_mlp(pnr_mlp m, Layout y, char* __restrict__ out, const fl
         } else {                                        // LIN_OUT: fragment f = k-step f, rows 0..3 valid
             if (row < 4) val = m.lin_out_w[(size_t)row * HID + 32 * f + perm_k(g, j)];
         }
+#ifdef PNR_DIAG_WMASK      // experiment only (tools/dev): weights rounded to 10 - PNR_DIAG_WMASK mantissa bits of the 16-bit format
+        {
+            uint32_t hb = Num<DT>::cvt(val);
+            hb = (hb + (1u << (PNR_DIAG_WMASK - 1))) & ~((1u << PNR_DIAG_WMASK) - 1u) & 0xffffu;
+            st[e] = (uint16_t)hb;
+            continue;
+        }
+#endif
         st[e] = Num<DT>::cvt(val);
     }
 }
@@ -395,6 +410,11 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Num<DT> NM;
+    // fp16: MODE.FP16_OVFL (bit 23 of HW_REG_MODE) for the whole kernel — a float -> fp16 conversion whose finite input
+    // overflows gives +-65504 instead of +-inf (a true inf stays inf), so the activations saturate inside v_cvt_pk_f16_f32 and
+    // the snapshot needs no v_pk_min per converted pair (tools/dev/ubench/ovfl_ubench.hip shows the behaviour on gfx950).
+    // hwreg(HW_REG_MODE = 1, offset 23, width 1) = 1 | 23 << 6 | 0 << 11.  The mode register is per wave and dies with it.
+    if (DT == PNR_F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Nothing per-lane stays live across the asm blocks (they clobber all but ~40 VGPRs, and a spilled value comes back
@@ -580,15 +600,25 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     const bool one_part = n_groups == 0;                    // a block has ONE lin_z part: its B image is written once per view
     // ---------------- compositing of this workgroup's finished rays (fused render launch): ray lr of the workgroup by wave
     // lr & 3, from what the waves stored to `out` (and z_out) — through the L2: see ld_f in pnr_common.h
+    const float4* cmp_c = (const float4*)(smem + LDS_BTAB + a.btab_floats * 4);      // the compositing ring (cmp_lds)
+    const float* cmp_z = (const float*)(cmp_c + CMP_RING);
     auto composite_rays = [&](int lr0, int lr1) __attribute__((always_inline)) {
         const int lane = lane_id();
         const int K = a.job.K;
         for (int lr = lr0 + ((wv - lr0) & 3); lr < lr1; lr += 4) {
             const int64_t ray = ray_begin + lr;
             const float far = flag(a.job.from_cam) ? a.job.cam.zf : a.src.rays[ray * 8 + 7];
-            const float* zr = (flag(a.job.gen_z) ? a.job.z_out : a.src.z) + ray * K;
-            const float4 r = composite_ray<true>(zr, (const float4*)a.out + ray * K, K, far, a.job.white_bkgd,
-                                                 a.job.w_out ? a.job.w_out + ray * a.job.w_stride : nullptr, lane);
+            float* wr = a.job.w_out ? a.job.w_out + ray * a.job.w_stride : nullptr;
+            float4 r;
+            if (flag(a.job.cmp_lds)) {
+                // on-chip route: sample k of the workgroup's ray lr is its point lr K + k, ring slot (lr K + k) mod CMP_RING
+                const int p0 = lr * K;
+                r = composite_ray_t([=](int k) { return cmp_z[(p0 + k) & (CMP_RING - 1)]; },
+                                    [=](int k) { return cmp_c[(p0 + k) & (CMP_RING - 1)]; }, K, far, a.job.white_bkgd, wr, lane);
+            } else {
+                const float* zr = (flag(a.job.gen_z) ? a.job.z_out : a.src.z) + ray * K;
+                r = composite_ray<true>(zr, (const float4*)a.out + ray * K, K, far, a.job.white_bkgd, wr, lane);
+            }
             if (lane == 0) {
                 float* po = a.job.rgb_out + ray * a.job.rgb_stride;
                 po[0] = r.x; po[1] = r.y; po[2] = r.z;
@@ -642,7 +672,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 if (lo < hi) {
 #pragma unroll
                     for (int cg = 0; cg < 2; ++cg) {
-                        const Taps tp = bilinear_taps(pu[cg], pv[cg], W, H);
+                        const Taps tp = bilinear_taps(pu[cg] * uv_sx(a.vw, lvl), pv[cg] * uv_sy(a.vw, lvl), W, H);
                         const char* lb = a.lat[lvl] + (size_t)view_of(c, cg, v) * H * W * C * 2;
                         // 4 k-steps (16 tap loads) in flight per iteration: the loop is latency-bound on L2 otherwise
                         for (int chb = lo + 8 * g; chb < hi; chb += 128) {
@@ -696,7 +726,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             for (int s = 0; s < 2 * p_steps; ++s) *(uint4*)(zwave + s * 1024 + lane * 16) = z4;
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) {
-                const Taps tp = bilinear_taps(pu[cg], pv[cg], a.vw.lat_w[ll], a.vw.lat_h[ll]);
+                const Taps tp = bilinear_taps(pu[cg] * uv_sx(a.vw, ll), pv[cg] * uv_sy(a.vw, ll), a.vw.lat_w[ll], a.vw.lat_h[ll]);
                 // one tap per instruction: horizontally adjacent texels are the two halves of ONE dword, and two lanes
                 // storing 16 bits each into the same dword in the same instruction lose one of the stores
 #pragma unroll
@@ -723,22 +753,28 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         };
         // ---- resblock b: [last lin_z part] + bias k-step + x += fc_1(relu(fc_0(relu(x))))  (resnetfc.py:53-62, 203-234)
         // n_pre consecutive blocks from b on with the lin_z prefix, then n_plain without, in ONE statement (its block loop)
-        auto resblocks = [&](int b, int n_pre, int n_plain) __attribute__((always_inline)) {
+        // prefetch: the statement also fetches the NEXT block's first gathered image back from the workspace into the wave's
+        // B-image buffer (16 LDS-DMA pieces in its two head stages: the buffer is free from there on), so that block's restore()
+        // disappears — see gen() in tools/gen_resblock_asm.py
+        auto resblocks = [&](int b, int n_pre, int n_plain, bool prefetch) __attribute__((always_inline)) {
             if (n_pre + n_plain == 0) return;
             PNR_LANE_OPERANDS;
             const uint32_t bias_addr = lds_addr(btab) + b * (HID * 4) + (ln_ >> 4) * 16;
             // k-steps of the prefix (the last lin_z part) that run as x-stages; with the bias folded into the projected columns
             // the last of them takes the place of the bias k-step (bit 24)
-            const int cfg2z = (a.proj ? p_steps - 1 : 8) | (n_pre << 16) | (n_plain << 20) | (a.proj ? 1 << 24 : 0);
+            const int cfg2z = (a.proj ? p_steps - 1 : 8) | (n_pre << 16) | (n_plain << 20) | (a.proj ? 1 << 24 : 0) | (prefetch ? 1 << 25 : 0);
+            const char* img_g = cache_wave;                        // image of group 0 (wave-uniform)
+            const uint32_t lane16 = (uint32_t)ln_ * 16;
+            const uint32_t img_l = __builtin_amdgcn_readfirstlane(lds_addr(zwave));
             if (DT == PNR_BF16)
                 asm volatile(PNR_RESBLOCK_ASM_BF16 : PNR_ASM_STATE_OPERANDS
                              : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
-                               "v"(zaddr), "s"(cfg2z)
+                               "v"(zaddr), "s"(cfg2z), "s"(img_g), "v"(lane16), "s"(img_l)
                              : PNR_RESBLOCK_CLOBBERS);
             else
                 asm volatile(PNR_RESBLOCK_ASM_F16 : PNR_ASM_STATE_OPERANDS
                              : "s"(asm_cfg), "s"(stream), "s"(ring_lds), "v"(ring_lane), "v"(gl_off), "v"(bias_addr), "v"(bias_dword),
-                               "v"(zaddr), "s"(cfg2z)
+                               "v"(zaddr), "s"(cfg2z), "s"(img_g), "v"(lane16), "s"(img_l)
                              : PNR_RESBLOCK_CLOBBERS);
         };
 
@@ -794,7 +830,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                                                           : rng_uniform(a.job.seed, global_ray(a.job.key, ray_begin + lr), DRAW_COARSE, k);
                             const float t = fmaf(u, 1.0f / (float)Kq, linspace_k(k, Kq));
                             zz = z_from_t(t, near, far, a.job.lindisp);
-                            if (v == 0 && g == 0 && in_range) a.job.z_out[gp] = zz;
+                            if (v == 0 && g == 0 && in_range && (!flag(a.job.cmp_lds) || flag(a.job.z_needed))) a.job.z_out[gp] = zz;
+                            // on-chip compositing: the tile epilogue picks the position up from the tile-input buffer's z slot
+                            // (unused when the positions are generated here; with PointSrc.z the prefetch has put it there)
+                            if (v == 0 && g == 0 && flag(a.job.cmp_lds)) *(float*)(const_cast<char*>(pts) + 1024 + pl * 4) = zz;
                         } else {
                             zz = *(const float*)(pts + 1024 + pl * 4);
                         }
@@ -868,11 +907,18 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             // statement serve both cases — a second call site would make hipcc merge the tiles from two paths (through scratch).
             const int b_step = one_part ? a.nb1 : 1;
             const int plain_here = (one_part && !MULTIVIEW) ? a.n_blocks - a.nb1 : 0;
+            // one gathered group in front of the block's last lin_z part (multi-scale): block b's statement prefetches block
+            // b + 1's image of that group while its chunks run
+#ifdef PNR_NO_IMAGE_PREFETCH      // A/B builds only (tools/dev, with the generator's `noprefetch`)
+            const bool pf = false;
+#else
+            const bool pf = n_groups == 1 && !one_part;
+#endif
             for (int b = 0; b < a.nb1; b += b_step) {
                 // ---- x += lin_z[b](z): all but the block's last part as separate x-stage calls
                 for (int grp = 0; grp < n_groups; ++grp) {
                     if (b == 0) gather(grp, true);
-                    else restore(grp);
+                    else if (!pf) restore(grp);
                     STAMP_ACC(10, st_t);
                     x_stages(8);
                     STAMP_ACC(11, st_t);
@@ -883,7 +929,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                     else restore(n_gather - 1);
                 }
                 STAMP_ACC(3, st_t);
-                resblocks(b, b_step, plain_here);
+                resblocks(b, b_step, plain_here, pf && b + 1 < a.nb1);
                 STAMP_ACC(6, st_t);
             }
         };
@@ -933,7 +979,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
         // ---- the blocks after the view reduction
         // (a loop, not an `if`: see view_pass; with no lin_z block at all the view pass has run none of them)
         for (int i = (MULTIVIEW || !one_part || a.nb1 == 0) ? 0 : 1; i < 1; ++i) {
-            resblocks(a.nb1, 0, a.n_blocks - a.nb1);
+            resblocks(a.nb1, 0, a.n_blocks - a.nb1, false);
             STAMP_ACC(6, st_t);
         }
 
@@ -959,7 +1005,16 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 res.y = 1.0f / (1.0f + __expf(-(o.y + bo[1])));
                 res.z = 1.0f / (1.0f + __expf(-(o.z + bo[2])));
                 res.w = fmaxf(o.w + bo[3], 0.f);
-                ((float4*)a.out)[gi] = res;
+                if (flag(a.job.cmp_lds)) {
+                    // fused render launch, K <= CMP_MAX_K: the point's output stays on the chip — (rgb, sigma) and z into the
+                    // compositing ring (read after the next tile's LIN_IN statement, whose entry waits and stage barriers order
+                    // these writes in front of the reads; the last tile's behind the loop's own wait + barrier)
+                    const int slot = li & (CMP_RING - 1);
+                    const_cast<float4*>(cmp_c)[slot] = res;
+                    const_cast<float*>(cmp_z)[slot] = *(const float*)(pts + 1024 + lane * 4);
+                } else {
+                    ((float4*)a.out)[gi] = res;
+                }
             }
         }
         STAMP_ACC(7, st_t);
@@ -969,7 +1024,7 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
     }
     if (a.job.on) {
         // the rays the last tile finished
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         composite_rays(rays_done, n_loc / a.job.K);
@@ -1109,7 +1164,14 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
         a.tiles_per_wg = (int)tpw;
         grid = (int)((a.n_tiles + tpw - 1) / tpw);
     }
-    const size_t lds = LDS_BTAB + (size_t)y.btab_floats * 4;
+    size_t lds = LDS_BTAB + (size_t)y.btab_floats * 4;
+    // compositing from the LDS ring: fused render launches whose rays are at most a tile long, where the ring fits behind the
+    // bias table; everything else composites from the (rgb, sigma) / z the launch leaves in global memory
+    a.job.cmp_lds = (a.job.on && a.job.K <= CMP_MAX_K && lds + CMP_BYTES <= (size_t)LDS_LIMIT) ? 1 : 0;
+#ifdef PNR_NO_LDS_COMPOSITE      // A/B builds only (tools/dev): every launch takes the memory route
+    a.job.cmp_lds = 0;
+#endif
+    if (a.job.cmp_lds) lds += CMP_BYTES;
     const void* fn;
     const bool mv = a.NS > 1;
     if (prm->precision == PNR_BF16) fn = mv ? (const void*)k_point_mfma<PNR_BF16, true> : (const void*)k_point_mfma<PNR_BF16, false>;

@@ -818,8 +818,9 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
         int c0 = 0;
         for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
             const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
-            Taps t = bilinear_taps(u, w, W, H);
-            TapsGrad tg = bilinear_taps_grad(u, w, W, H);
+            const float usx = uv_sx(vw, lvl), usy = uv_sy(vw, lvl);      // d(texel coordinate) / d(uv)
+            Taps t = bilinear_taps(u * usx, w * usy, W, H);
+            TapsGrad tg = bilinear_taps_grad(u * usx, w * usy, W, H);
             for (int ch = lane; ch < C; ch += 64) {
                 float gz = drow[c0 + ch];
                 size_t base = ((size_t)view * C + ch) * (size_t)(H * W);
@@ -837,8 +838,8 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
                         sx += val * tg.dx[i];
                         sy += val * tg.dy[i];
                     }
-                    du += gz * sx;
-                    dv += gz * sy;
+                    du += gz * (sx * usx);
+                    dv += gz * (sy * usy);
                 }
             }
             c0 += C;
@@ -904,7 +905,7 @@ static __global__ void __launch_bounds__(256) k_latent_grad_lds(
         fetch_point(src, g0 + threadIdx.x, p, d);
         rot3(cam.R, p, xr);
         project(cam, xr, u, w);
-        const Taps t = bilinear_taps(u, w, W, H);
+        const Taps t = bilinear_taps(u * uv_sx(vw, 0), w * uv_sy(vw, 0), W, H);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { tap_off[threadIdx.x * 4 + i] = t.off[i]; tap_w[threadIdx.x * 4 + i] = t.w[i]; }
     }
@@ -1125,8 +1126,26 @@ static uint64_t det_ws_floats(const pnr_mlp* mlp) {
 }
 
 // one small single-level map: the latent gradient runs on per-block partial maps (k_latent_grad_lds); bytes of the slices
+// dynamic LDS k_latent_grad_lds needs for this map: the [T][C] accumulator + the tap table of a block's points
+static size_t latent_grad_lds_bytes(const pnr_views* vw) {
+    return (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 + (size_t)LATG_PPB * 4 * 8;
+}
+// LDS a block may ask for on this device (gfx950: 160 KiB), cached per device like num_cus() — an immutable property
+static size_t lds_per_block_limit() {
+    static size_t cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64 * 1024;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || n <= 0) n = 64 * 1024;
+        cached[dev] = (size_t)n;
+    }
+    return cached[dev];
+}
 static bool latent_grad_in_lds(const pnr_views* vw) {
-    return vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024;
+    // the real requirement (map + tap table) against what the device grants; maps up to 64 KiB as before
+    return vw->n_levels == 1 && (size_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4 <= 64 * 1024 &&
+           latent_grad_lds_bytes(vw) <= lds_per_block_limit();
 }
 static uint64_t latent_part_bytes(const pnr_views* vw, int64_t P) {
     if (!latent_grad_in_lds(vw) || vw->n_objs < 1) return 0;
@@ -1324,7 +1343,6 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     return finish(nz);
 }
 
-#define PNR_TRY(expr) do { int32_t _rc = (expr); if (_rc) return _rc; } while (0)
 
 // bf16 copy of a fp32 tensor (the residual stream behind a view reduction, or lin_in's output when no lin_z follows)
 static __global__ void k_to_bf16(const float* __restrict__ x, int64_t n, uint16_t* __restrict__ y) {
@@ -1342,7 +1360,7 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
-    features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s);
+    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s));
     PNR_LAUNCH_CHECK();
     auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
         hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
@@ -1413,7 +1431,7 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
     // GEMM products: 0 = fp32 MFMA, 1 = bf16 MFMA, 3 = bf16x3 split (fp32-class) — all on the fp32 tape
     const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
-    features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s);
+    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s));
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
@@ -1516,9 +1534,18 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     // small single-level map: latent gradient on per-block partial maps + an ordered reduction (bit-reproducible)
     if (want_lat && L > 0 && latent_grad_in_lds(vw)) {
         const int T = vw->lat_h[0] * vw->lat_w[0], C = vw->lat_c[0], views = vw->n_objs * vw->n_views;
-        const size_t lds = (size_t)C * T * 4 + (size_t)LATG_PPB * 4 * 8;
+        const size_t lds = latent_grad_lds_bytes(vw);
         const int nbx = (int)((pts_per_obj + LATG_PPB - 1) / LATG_PPB);
-        PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_latent_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024) {          // only above the default limit, and once per device (the attribute sticks to the function)
+            static bool raised[64] = {false};
+            int dev = 0;
+            PNR_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !raised[dev]) {
+                PNR_HIP_CHECK(hipFuncSetAttribute((const void*)k_latent_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)lds_per_block_limit()));
+                if (dev >= 0 && dev < 64) raised[dev] = true;
+            }
+        }
         hipLaunchKernelGGL(k_latent_grad_lds, dim3(nbx, views), dim3(256), lds, s, *vw, src, P, pts_per_obj, L, dzx, E, lat_part);
         PNR_LAUNCH_CHECK();
         const int64_t tot = (int64_t)views * T * C;

@@ -22,9 +22,15 @@ import torch
 class FinishLog:
     """finish.txt: append-only per-object results with resume (objects already listed are skipped by the driver)."""
 
-    def __init__(self, path):
+    def __init__(self, path, state=None):
+        """state = (finished, total_psnr, total_ssim, cnt): a follower of a multi-rank evaluation — it starts from the
+        owner's view of the file (broadcast once) and never opens it: the file has ONE writer."""
         self.path = path
         self.finished, self.total_psnr, self.total_ssim, self.cnt = set(), 0.0, 0.0, 0
+        self._f = None
+        if state is not None:
+            self.finished, self.total_psnr, self.total_ssim, self.cnt = set(state[0]), float(state[1]), float(state[2]), int(state[3])
+            return
         if os.path.exists(path):
             with open(path) as f:
                 rows = [x.strip().split() for x in f.readlines()]
@@ -36,8 +42,12 @@ class FinishLog:
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         self._f = open(path, "a", buffering=1)
 
+    def state(self):
+        return (sorted(self.finished), self.total_psnr, self.total_ssim, self.cnt)
+
     def append(self, obj_name, psnr, ssim, cnt=1):
-        self._f.write("{} {} {} {}\n".format(obj_name, psnr, ssim, cnt))
+        if self._f is not None:
+            self._f.write("{} {} {} {}\n".format(obj_name, psnr, ssim, cnt))
         self.finished.add(obj_name)
         self.total_psnr += psnr
         self.total_ssim += ssim
@@ -47,7 +57,8 @@ class FinishLog:
         return (self.total_psnr / self.cnt, self.total_ssim / self.cnt) if self.cnt else (0.0, 0.0)
 
     def close(self):
-        self._f.close()
+        if self._f is not None:
+            self._f.close()
 
 
 def read_source_view_lut(path):
@@ -130,7 +141,7 @@ def write_png(path, rgb_u8):
 def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None, eval_view_list=None,
              include_src=False, scale=1.0, multicat=False, gpu_id=None, ray_batch_size=50000, no_compare_gt=False,
              write_compare=False, write_images=True, max_objects=50, z_near=None, z_far=None,
-             verbose=True):
+             verbose=True, seed=None):
     """The per-object evaluation loop of the reference (eval/eval.py:186-362) on this package's renderer.
 
     dataset: a sequence of per-object dicts as the reference's datasets yield them (unbatched): "path", "images"
@@ -142,15 +153,18 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
     source views from `source` ("0 1 2") or the look-up table file / dict `viewlist` keyed "<cat>/<obj>" (:156-165,
     :224-231); target views = eval_view_list (file / indices) minus the source views unless include_src (:170-178,
     :246-248); net.encode on the source images (:271-276); every target view rendered — as ONE call per view with the rays
-    generated inside the render launch (NeRFRenderer.render_image) on one device, or through renderer.bind_parallel(net,
-    gpu_id, simple_output=True) in chunks of ray_batch_size when a process group is up (:151, :267, :279-284) — with the
+    generated inside the render launch (NeRFRenderer.render_image) on one device, or, when a process group is up, through the
+    sharded form of renderer.bind_parallel(net, gpu_id, simple_output=True) in chunks of ray_batch_size (:151, :267,
+    :279-284: every chunk cut over the ranks, one all_gather each; rank 0 alone writes finish.txt and the PNGs, the other
+    ranks take the resume state from it by one broadcast) — with the
     frames brought to the host asynchronously (frame_to_host_async) while the next view renders; clamp to [0, 1] and
     reshape (:286-293); PNGs "<obj>/<view:06>.png" quantised by truncation (:294-301); PSNR / SSIM per view against
     images * 0.5 + 0.5, averaged per object (:318-347); running means and a "<obj> <psnr> <ssim> 1" line appended to
     finish.txt (:348-362).  Returns (mean_psnr, mean_ssim, n_objects_counted) over everything in finish.txt.
 
     Deliberate differences: the rays of all target views are not concatenated and re-split (:250-267) — a view is the unit;
-    the random jitter is keyed by (seed, ray) so chunking does not change results; SSIM is this module's restatement
+    the random jitter is keyed by (seed, ray): one base seed per call (`seed`, else drawn from torch's generator on rank 0
+    and broadcast) and a seed derived per (object, view), so neither the chunk size, nor the number of ranks, nor a resume changes a pixel; SSIM is this module's restatement
     (skimage is not importable here: parity unpinned); depth EXR / colour-mapped depth outputs (:303-316) are not written."""
     import torch.distributed as dist
     from . import util
@@ -158,7 +172,28 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
     z_near = float(getattr(dataset, "z_near", None) if z_near is None else z_near)
     z_far = float(getattr(dataset, "z_far", None) if z_far is None else z_far)
     has_output = bool(output_dir and str(output_dir).strip())
-    log = FinishLog(os.path.join(output_dir, "finish.txt")) if has_output else None
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if sharded else 0
+    # Under a process group every rank runs this loop (each call's rays are cut over the ranks and every rank gets the whole
+    # frame back), but the output directory has ONE writer: rank 0 owns finish.txt and the PNGs; the other ranks start from
+    # rank 0's view of the file — broadcast once, so all ranks skip the same objects whatever the file system shows them —
+    # and keep their running means in memory.  The return value is the same on every rank.
+    log = None
+    if has_output:
+        if rank == 0:
+            log = FinishLog(os.path.join(output_dir, "finish.txt"))
+        if sharded:
+            box = [log.state() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                log = FinishLog(os.path.join(output_dir, "finish.txt"), state=box[0])
+    writes_files = has_output and rank == 0
+    from .parallel import frame_seed
+    base_seed = int(seed) if seed is not None else util.seed_from_torch()
+    if sharded and seed is None:
+        box = [base_seed]
+        dist.broadcast_object_list(box, src=0)
+        base_seed = int(box[0])
     total_psnr, total_ssim, cnt = (log.total_psnr, log.total_ssim, log.cnt) if log else (0.0, 0.0, 0)
     if log and log.cnt > 0 and verbose:
         print("resume psnr", log.total_psnr / log.cnt, "ssim", log.total_ssim / log.cnt)
@@ -169,8 +204,12 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
     fixed_source = None if use_lut else torch.tensor(sorted(int(x) for x in str(source).split()), dtype=torch.long)
     if isinstance(eval_view_list, str):
         eval_view_list = read_eval_view_list(eval_view_list)
-    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    render_par = renderer.bind_parallel(net, gpu_id, simple_output=True).eval() if sharded else None
+    render_par = None
+    if sharded:
+        # built directly: bind_parallel() only shards when the caller lists several gpu ids (eval.py:151 passes args.gpu_id),
+        # and a rank of a one-process-per-GPU job has exactly one
+        from .render.nerf import _ShardedRenderWrapper
+        render_par = _ShardedRenderWrapper(net, renderer, simple_output=True).eval()
     was_training = net.training
     net.eval()
     try:
@@ -213,15 +252,37 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
                 poses = torch.as_tensor(data["poses"]).float()
                 net.encode(images[src_mask].to(dev).unsqueeze(0), poses[src_mask].to(dev).unsqueeze(0), focal[None].to(dev),
                            c=None if c is None else c.to(dev).unsqueeze(0))
+                if sharded:
+                    # every rank ran the trunk on the same images, but a convolution library may pick different algorithms in
+                    # different processes (last-bit differences): rank 0's maps are THE maps, so that the gathered frame is one
+                    # consistent render (64 KB ... 6 MB per object, once — SURVEY 8e)
+                    maps = [m.detach().clone() for m in net.encoder.level_maps()]
+                    for m in maps:
+                        if dist.get_backend() == "nccl":
+                            dist.broadcast(m, src=0)
+                        else:
+                            h = m.cpu()
+                            dist.broadcast(h, src=0)
+                            m.copy_(h)
+                    net.encoder.set_latents(maps)
                 frames, pending = [], None
                 for vi in novel.tolist():
+                    # keyed by (object, view), not by a running count: a resumed run draws what the uninterrupted run drew
+                    view_seed = frame_seed(frame_seed(base_seed, obj_idx), vi)
                     if render_par is None:
-                        rgb, depth = renderer.render_image(net, poses[vi], W, H, focal * scale, z_near, z_far,
-                                                           c=None if c is None else c * scale)
+                        keep_seed, renderer.forced_seed = renderer.forced_seed, view_seed
+                        try:
+                            rgb, depth = renderer.render_image(net, poses[vi], W, H, focal * scale, z_near, z_far,
+                                                               c=None if c is None else c * scale)
+                        finally:
+                            renderer.forced_seed = keep_seed
                     else:
                         rays = util.gen_rays_device(poses[vi], W, H, focal * scale, z_near, z_far,
                                                     c=None if c is None else c * scale, device=dev)
-                        parts = [render_par(r[None]) for r in torch.split(rays, ray_batch_size, dim=0)]
+                        parts, at = [], 0
+                        for r in torch.split(rays, ray_batch_size, dim=0):
+                            parts.append(render_par(r[None], ray_index_base=at, seed=view_seed))
+                            at += r.shape[0]
                         rgb = torch.cat([p[0][0] for p in parts], 0).reshape(H, W, 3)
                         depth = torch.cat([p[1][0] for p in parts], 0).reshape(H, W)
                     nxt = renderer.frame_to_host_async(rgb, depth)          # D2H overlaps the next view's render
@@ -234,7 +295,7 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
                     frames.append(pending[0])
                 all_rgb = torch.clamp(torch.stack(frames), 0.0, 1.0).numpy() if frames else np.zeros((0, H, W, 3), np.float32)
                 n_gen = len(frames)
-                if has_output and write_images:
+                if writes_files and write_images:
                     obj_out = os.path.join(output_dir, obj_name)
                     os.makedirs(obj_out, exist_ok=True)
                     for i in range(n_gen):
@@ -245,7 +306,7 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
                     for i in range(n_gen):
                         curr_ssim += ssim(all_rgb[i], gt[i], data_range=1)
                         curr_psnr += psnr(all_rgb[i], gt[i], data_range=1)
-                        if has_output and write_compare:
+                        if writes_files and write_compare:
                             write_png(os.path.join(output_dir, obj_name, "{:06}_compare.png".format(int(novel[i]))),
                                       quantize_uint8(np.hstack((all_rgb[i], gt[i]))))
                     curr_psnr /= n_gen
@@ -261,6 +322,8 @@ def evaluate(net, renderer, dataset, output_dir="", *, source="", viewlist=None,
         net.train(was_training)
         if log:
             log.close()
+    if sharded:
+        dist.barrier()              # rank 0's files are complete when any rank returns
     if verbose and cnt:
         print("final psnr", total_psnr / cnt, "ssim", total_ssim / cnt)
     return (total_psnr / cnt, total_ssim / cnt, cnt) if cnt else (0.0, 0.0, 0)

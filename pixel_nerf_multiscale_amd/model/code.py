@@ -1,6 +1,7 @@
 import math
 
 import torch
+from torch.autograd.profiler import record_function
 
 from ..util import as_conf
 
@@ -22,6 +23,11 @@ class PositionalEncoding(torch.nn.Module):
         self.register_buffer("_phases", ph.view(1, -1, 1))
 
     def forward(self, x):
+        """PositionalEncoding.forward under the reference's profiler label (code.py:40)."""
+        with record_function("positional_enc"):
+            return self._forward_impl(x)
+
+    def _forward_impl(self, x):
         if x.numel() == 0:
             return x.new_empty(x.shape[0], self.d_out)
         e = torch.sin(self._phases + x[:, None, :] * self._freqs).flatten(1)

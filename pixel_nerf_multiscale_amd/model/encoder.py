@@ -77,6 +77,11 @@ class SpatialEncoder(nn.Module):
         # from, and are handed over without a repack (pnr_views.latent_packed).
         self.half_dtype = None
         self._level_maps16 = None
+        # "latent" = the reference fork's lookup (uv normalised by the latent size: texel coordinate = image-pixel
+        # coordinate, image_size ignored — encoder.py:152-164), the default and the parity target; "image" = upstream
+        # pixelNeRF's (texel = uv * latent_size / image_size), for checkpoints trained with upstream semantics.  Honoured by
+        # index() and by every render / training kernel (pnr_views.uv_scale_x / _y).  Parity unpinned for "image".
+        self.uv_scale = "latent"
 
     def forward(self, x):
         x = x * self.feature_scale
@@ -123,6 +128,7 @@ class SpatialEncoder(nn.Module):
     def index(self, uv, cam_z=None, image_size=(), z_bounds=None):
         """uv (B, N, 2) image points -> (B, L, N) pixel-aligned features (reference encoder.py:138-205; bilinear, border
         padding, align_corners, every level normalised by its own latent size): a native stage call (pnr_index_latent).
+        image_size is ignored like in the reference unless self.uv_scale == "image" (upstream's mapping, opt-in).
         Inference only; inside the render path the lookup is fused into the point kernels."""
         import ctypes as C
         from .. import _native as N
@@ -141,6 +147,12 @@ class SpatialEncoder(nn.Module):
             keep.append(mp)
             v.latent[i] = N.ptr(mp)
             v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+            if self.uv_scale == "image":
+                if len(image_size) != 2:
+                    raise ValueError('uv_scale = "image" needs image_size = (W, H)')
+                v.uv_scale_x[i], v.uv_scale_y[i] = mp.shape[3] / float(image_size[0]), mp.shape[2] / float(image_size[1])
+            elif self.uv_scale != "latent":
+                raise ValueError(f"uv_scale must be 'latent' or 'image', got {self.uv_scale!r}")
         q = N.f32c(uv.detach())
         n = q.shape[1]
         out = torch.empty(nv, sum(int(m.shape[1]) for m in maps), n, device=dev)

@@ -9,6 +9,7 @@ import os.path as osp
 import warnings
 
 import torch
+from torch.autograd.profiler import record_function
 
 from .. import _native as N
 from ..util import as_conf
@@ -230,7 +231,7 @@ class PixelNeRFNet(torch.nn.Module):
         """pnr_views over what encode() left on the module (+ the packed 16-bit maps); cached like mlp_struct."""
         maps = self.encoder.level_maps()
         maps16 = self.encoder.level_maps16(torch.float16 if precision in ("fp16", "f16") else torch.bfloat16) if precision != "fp32" else None
-        skey = ("vstruct", precision, int(self.num_views_per_obj),
+        skey = ("vstruct", precision, int(self.num_views_per_obj), self.uv_scales(),
                 tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.poses, self.focal, self.c, *maps)),
                 None if maps16 is None else tuple(m.data_ptr() for m in maps16))
         hit = self._struct_cache.get(skey)
@@ -244,7 +245,7 @@ class PixelNeRFNet(torch.nn.Module):
     def _build_views_struct(self, precision):
         maps = self.encoder.level_maps()
         dev = maps[0].device
-        v, keep = views_from(self.poses, self.focal, self.c, self.num_views_per_obj, maps)
+        v, keep = views_from(self.poses, self.focal, self.c, self.num_views_per_obj, maps, self.uv_scales())
         if precision != "fp32":
             tdt = torch.float16 if precision in ("fp16", "f16") else torch.bfloat16
             maps16 = self.encoder.level_maps16(tdt)
@@ -272,6 +273,20 @@ class PixelNeRFNet(torch.nn.Module):
                 keep.append(packed)
             v.packed_dtype = N.PRECISIONS[precision]
         return v, keep
+
+    def uv_scales(self):
+        """Per-level (sx, sy) of pnr_views.uv_scale, or None for the fork's mapping.  encoder.uv_scale = "latent" (default):
+        the reference fork's SpatialEncoder.index normalises uv by the LATENT size and ignores image_size
+        (encoder.py:152-164), so the sampled texel coordinate equals the image-pixel coordinate — the parity
+        target.  "image": upstream pixelNeRF's mapping, texel = uv * latent_size / image_size per level — what a checkpoint
+        trained with upstream semantics expects.  Parity unpinned: the reference holds no fixture for that mapping."""
+        mode = getattr(self.encoder, "uv_scale", "latent")
+        if mode == "latent":
+            return None
+        if mode != "image":
+            raise ValueError(f"encoder.uv_scale must be 'latent' or 'image', got {mode!r}")
+        W, H = float(self.image_shape[0]), float(self.image_shape[1])
+        return tuple((m.shape[3] / W, m.shape[2] / H) for m in self.encoder.level_maps())
 
     def wants_grad(self, *inputs):
         """True when the call must go through the differentiable (fp32, taped) path: the module is in training
@@ -302,19 +317,37 @@ class PixelNeRFNet(torch.nn.Module):
         """Scratch of a native call, one buffer per (device, stream, host thread): the C ABI is re-entrant (the caller owns
         the workspace), so two streams — or two threads — rendering through ONE net must not be handed the same bytes."""
         import threading
+        from collections import OrderedDict
         device = torch.device(device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, int(torch.cuda.current_stream(idx).cuda_stream), threading.get_ident())
         if self._ws is None:
-            self._ws = {}
+            self._ws = OrderedDict()
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             self._ws[key] = ws
+        # least-recently-used bound: short-lived threads / streams would otherwise each leave a full-size buffer behind (a
+        # multi-view workspace is hundreds of MB).  An evicted buffer still referenced by a running call stays alive through
+        # that reference; callers with more than max_workspaces concurrent streams should raise the bound.
+        self._ws.move_to_end(key)
+        while len(self._ws) > max(1, int(self.max_workspaces)):
+            self._ws.popitem(last=False)
         return ws
+
+    max_workspaces = 8
+
+    def release_workspaces(self):
+        """Drop every cached native-call workspace of this net (they are re-created on demand)."""
+        self._ws = None
 
     # ------------------------------------------------------------------ per-point evaluation (backup2:155-282)
     def forward(self, xyz, coarse=True, viewdirs=None, far=False):
+        """PixelNeRFNet.forward under the reference's profiler label (models.py.backup2:165)."""
+        with record_function("model_inference"):
+            return self._forward_impl(xyz, coarse, viewdirs, far)
+
+    def _forward_impl(self, xyz, coarse=True, viewdirs=None, far=False):
         """xyz (SB, B, 3) world points [, viewdirs (SB, B, 3)] -> (SB, B, 4) = sigmoid(rgb), relu(sigma)."""
         assert viewdirs is not None, "use_viewdirs is on: viewdirs required"
         SB, B, _ = xyz.shape
@@ -363,8 +396,9 @@ class PixelNeRFNet(torch.nn.Module):
         return self
 
 
-def views_from(poses, focal, c, num_views_per_obj, maps):
-    """pnr_views over explicit camera tensors (as encode() leaves them) and fp32 latent maps."""
+def views_from(poses, focal, c, num_views_per_obj, maps, uv_scale=None):
+    """pnr_views over explicit camera tensors (as encode() leaves them) and fp32 latent maps.  uv_scale: None (the fork's
+    texel mapping) or one (sx, sy) per level (PixelNeRFNet.uv_scales)."""
     dev = maps[0].device
     v = N.pnr_views()
     keep = []
@@ -384,6 +418,8 @@ def views_from(poses, focal, c, num_views_per_obj, maps):
         keep.append(mp)
         v.latent[i] = N.ptr(mp)
         v.lat_c[i], v.lat_h[i], v.lat_w[i] = mp.shape[1], mp.shape[2], mp.shape[3]
+        if uv_scale is not None:
+            v.uv_scale_x[i], v.uv_scale_y[i] = float(uv_scale[i][0]), float(uv_scale[i][1])
     return v, keep
 
 

@@ -1,4 +1,5 @@
 import torch
+from torch.autograd.profiler import record_function
 from torch import nn
 
 from ..util import as_conf
@@ -83,6 +84,11 @@ class ResnetFC(nn.Module):
         return m, keep
 
     def forward(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
+        """ResnetFC.forward under the reference's profiler label (resnetfc.py:180)."""
+        with record_function("resnetfc_infer"):
+            return self._forward_impl(zx, combine_inner_dims, combine_index, dim_size)
+
+    def _forward_impl(self, zx, combine_inner_dims=(1,), combine_index=None, dim_size=None):
         """zx (..., d_latent + d_in), latent first -> (..., d_out) with the `combine_inner_dims` reduction of the reference
         (resnetfc.py:173-236, util.combine_interleaved): a native stage call (pnr_resnetfc_forward, fp32 kernels) — the
         module is not evaluated in PyTorch.  Inference only; the differentiable network is PixelNeRFNet.forward in

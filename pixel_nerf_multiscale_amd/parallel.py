@@ -9,6 +9,8 @@ per call — an all_gather of (SB * B/world, 4) fp32 [rgb, depth] records that t
 collective's input buffer — reassembles the pixels on every rank.  With the same seed the gathered batch is
 bit-identical to the 1-GPU one.  Training is data-parallel instead (one batch per rank, allreduce_gradients below).
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -43,6 +45,9 @@ class ShardedRenderer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.frame_idx = 0
+        # bench / diagnosis: a list here makes gather() append one (begin, end) pair of events per collective, recorded on the
+        # stream the collective is ordered on (device messages), or one host-clock duration in ms (host-memory backends)
+        self.collective_timing = None
         if base_seed is None:
             t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
             if self.world > 1:
@@ -78,17 +83,22 @@ class ShardedRenderer:
             return True
         return cls(render_shard, render_into=render_into, **kw)
 
-    def gather(self, rays, widths):
+    def gather(self, rays, widths, index_base=0, seed=None):
         """rays (SB, B, 8), cut along B: rank k renders rays[:, lo_k:hi_k] of EVERY object (nn.DataParallel(dim=1),
         reference render/nerf.py:367-371) with the generator keyed by the rays' indices in the unsharded batch.  ONE
         all_gather of (SB * ceil(B/world), sum(widths)) fp32 per rank, straight from the buffer the render launch wrote;
-        returns the full (SB, B, w) / (SB, B) tensors on every rank (views of the gathered buffer when SB == 1)."""
+        returns the full (SB, B, w) / (SB, B) tensors on every rank (views of the gathered buffer when SB == 1).
+        index_base / seed: this call's rays are rays [index_base, index_base + B) of a larger frame rendered under `seed`
+        (a driver that walks a frame in chunks, eval/eval.py:267-284): the draws then are those of the whole-frame render,
+        whatever the chunk size and the number of ranks.  Every rank must pass the same values."""
         assert rays.dim() == 3, "rays (SB, B, 8)"
         SB, B = rays.shape[0], rays.shape[1]
         lo, hi, per = shard_range(B, self.world, self.rank)
         n = hi - lo
-        seed = frame_seed(self.base_seed, self.frame_idx)
-        self.frame_idx += 1
+        if seed is None:
+            seed = frame_seed(self.base_seed, self.frame_idx)
+            self.frame_idx += 1
+        index_base = int(index_base)
         tot = int(sum(widths))
         obj_stride = B if SB > 1 else 0
         # the rank's own records get their own buffer at world > 1: an all_gather whose input aliases its output is legal for
@@ -100,23 +110,41 @@ class ShardedRenderer:
         if n > 0:
             shard = rays[:, lo:hi] if SB == 1 else rays[:, lo:hi].contiguous()
             slab = mine[: SB * n].view(SB, n, tot)
-            if not (self.render_into is not None and self.render_into(shard, lo, seed, obj_stride, slab)):
-                outs = self.render_shard(shard.contiguous(), lo, seed) if obj_stride == 0 else \
-                    self.render_shard(shard.contiguous(), lo, seed, obj_stride)
+            if not (self.render_into is not None and self.render_into(shard, index_base + lo, seed, obj_stride, slab)):
+                outs = self.render_shard(shard.contiguous(), index_base + lo, seed) if obj_stride == 0 else \
+                    self.render_shard(shard.contiguous(), index_base + lo, seed, obj_stride)
                 assert len(outs) == len(widths)
                 off = 0
                 for t, w in zip(outs, widths):
                     slab[..., off:off + w] = t.reshape(SB, n, w)
                     off += w
         if self.world > 1:
+            timing = self.collective_timing
             if full.is_cuda and dist.get_backend(self.group) != "nccl":
                 # a host-memory backend (gloo) under device tensors — rehearsing the multi-rank path with several ranks on
                 # one card, where RCCL refuses duplicate devices: the (small) message travels through the host
                 host = torch.empty(self.world, SB * per, tot, dtype=torch.float32)
-                dist.all_gather_into_tensor(host.view(-1), mine.cpu().view(-1), group=self.group)
+                mine_h = mine.cpu()
+                t0 = time.perf_counter()
+                dist.all_gather_into_tensor(host.view(-1), mine_h.view(-1), group=self.group)
+                if timing is not None:
+                    timing.append((time.perf_counter() - t0) * 1e3)
                 full = host.to(rays.device)
-            else:
+            elif full.is_cuda:
+                # the collective is ordered behind the render launch on the current stream and the stream waits for it
+                # (async_op=False), so a pair of events on that stream brackets exactly the all_gather
+                if timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch.cuda.current_stream(full.device))
                 dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=self.group)
+                if timing is not None:
+                    e1.record(torch.cuda.current_stream(full.device))
+                    timing.append((e0, e1))
+            else:
+                t0 = time.perf_counter()
+                dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=self.group)
+                if timing is not None:
+                    timing.append((time.perf_counter() - t0) * 1e3)
         if SB == 1:
             recs = full.view(self.world * per, tot)[:B].unsqueeze(0)                            # (1, B, tot), a view
         else:

@@ -74,7 +74,7 @@ class PointMLP(torch.autograd.Function):
         dev = a.device
         a, b = N.f32c(a.detach()), N.f32c(b.detach())
         m, k1 = _mlp_struct_from(hdr, params)
-        v, k2 = views_from(poses, focal, c, hdr["n_views"], maps)
+        v, k2 = views_from(poses, focal, c, hdr["n_views"], maps, hdr["uv_scale"])
         rays_mode = hdr["rays_mode"]
         if rays_mode:
             n_rays, K = b.shape
@@ -104,7 +104,7 @@ class PointMLP(torch.autograd.Function):
         params, maps = rest[:n_par], rest[n_par:]
         dev = a.device
         m, k1 = _mlp_struct_from(hdr, params)
-        v, k2 = views_from(poses, focal, c, hdr["n_views"], maps)
+        v, k2 = views_from(poses, focal, c, hdr["n_views"], maps, hdr["uv_scale"])
         need = ctx.needs_input_grad            # (hdr, a, b, poses, focal, c, *params, *maps)
         need_par, need_map = need[6:6 + n_par], need[6 + n_par:]
         # one zero fill for all parameter gradients (the kernels accumulate with atomics)
@@ -210,7 +210,8 @@ def _header(net, mlp, rays_mode):
     return dict(d_in=mlp.d_in, d_latent=mlp.d_latent, d_hidden=mlp.d_hidden, d_out=mlp.d_out, n_blocks=mlp.n_blocks,
                 combine_layer=mlp.combine_layer, combine_type=mlp.combine_type,
                 n_lin_z=len(mlp.lin_z) if mlp.d_latent else 0, n_params=len(mlp_tensors(mlp)),
-                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=_train_params(net))
+                n_views=int(net.num_views_per_obj), rays_mode=rays_mode, prm=_train_params(net),
+                uv_scale=net.uv_scales())
 
 
 def point_mlp_rays(net, mlp, rays, z):

@@ -9,6 +9,7 @@ libpnr_hip.so:
 import ctypes as C
 
 import torch
+from torch.autograd.profiler import record_function
 
 from .. import _native as N
 from ..util import AttrDict, as_conf, seed_from_torch
@@ -95,14 +96,16 @@ class _ShardedRenderWrapper(torch.nn.Module):
             self._keyed(0, None, 0)
         return True
 
-    def forward(self, rays, want_weights=False):
+    def forward(self, rays, want_weights=False, ray_index_base=0, seed=None):
+        """ray_index_base / seed (this package's drivers only): the call's rays are a chunk of a frame rendered under
+        `seed`, starting at that ray index — see ShardedRenderer.gather."""
         if rays.shape[0] == 0:
             return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
         if getattr(self.net, "wants_grad", None) is not None and self.net.wants_grad(rays):
             return self.local(rays, want_weights)          # training: rank-local, see the class docstring
         # per-sample weights (nested output only, nerf.py:33-41) travel in the same all_gather as rgb and depth
         self._want_weights = bool(want_weights) and not self.simple_output
-        cols = self.sharded.gather(rays, self._widths())
+        cols = self.sharded.gather(rays, self._widths(), index_base=ray_index_base, seed=seed)
         if self.simple_output:
             return cols[0], cols[1]
         per = 3 if self._want_weights else 2
@@ -180,6 +183,11 @@ class NeRFRenderer(torch.nn.Module):
         return z
 
     def composite(self, model, rays, z_samp, coarse=True, sb=0):
+        """Generic-model compositing under the reference's profiler label (nerf.py:175)."""
+        with record_function("renderer_composite"):
+            return self._composite_impl(model, rays, z_samp, coarse, sb)
+
+    def _composite_impl(self, model, rays, z_samp, coarse=True, sb=0):
         """Generic-model compositing (nerf.py:163-249): chunked model calls + the HIP compositing stage."""
         rays, z_samp = N.f32c(rays), N.f32c(z_samp)
         B, K = z_samp.shape
@@ -213,6 +221,11 @@ class NeRFRenderer(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward (nerf.py:251-303)
     def forward(self, model, rays, want_weights=False):
+        """NeRFRenderer.forward (nerf.py:251-303) under the reference's profiler label (nerf.py:264)."""
+        with record_function("renderer_forward"):
+            return self._forward_impl(model, rays, want_weights)
+
+    def _forward_impl(self, model, rays, want_weights=False):
         if self.sched is not None and self.last_sched.item() > 0:
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]

@@ -227,3 +227,19 @@ def load_rays_fixture():
                           H=int(z[f"{name}__WH"][1]), focal=z[f"{name}__focal"], c=None if c.size == 0 else c,
                           z_near=float(z[f"{name}__z"][0]), z_far=float(z[f"{name}__z"][1]), rays=z[f"{name}__rays"]))
     return cases
+
+
+def noise_from_fixture(fx):
+    """Map the recorded draws (reference draw order, nerf.py:111,135,141,158) to named noise."""
+    order = str(fx["noise_order"]).split(",")
+    spec = fx["spec"]
+    n_imp = spec["Kf"] - spec["Kfd"]
+    names = ["noise_c"]
+    if spec["Kf"] > 0:
+        if n_imp > 0:
+            names += ["u", "r"]
+        if spec["Kfd"] > 0:
+            names += ["g"]
+    assert len(names) == len(order), (names, order)
+    import torch
+    return {n: torch.from_numpy(fx[f"noise{i}_{k}"]) for i, (n, k) in enumerate(zip(names, order))}

@@ -3,7 +3,7 @@ latents and cameras the reference was run with)."""
 import torch
 
 import golden_util as gu
-from oracle_util import noise_from_fixture
+from golden_util import noise_from_fixture      # fixture plumbing only: bench.py builds its workloads here without importing oracle/
 
 
 def model_conf(spec, precision="fp32"):

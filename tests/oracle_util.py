@@ -3,22 +3,8 @@ import numpy as np
 import torch
 
 import golden_util as gu
+from golden_util import noise_from_fixture  # noqa: F401  (fixture plumbing, not oracle code)
 from oracle import pixelnerf_oracle as orc
-
-
-def noise_from_fixture(fx):
-    """Map the recorded draws (reference draw order, nerf.py:111,135,141,158) to named noise."""
-    order = str(fx["noise_order"]).split(",")
-    spec = fx["spec"]
-    n_imp = spec["Kf"] - spec["Kfd"]
-    names = ["noise_c"]
-    if spec["Kf"] > 0:
-        if n_imp > 0:
-            names += ["u", "r"]
-        if spec["Kfd"] > 0:
-            names += ["g"]
-    assert len(names) == len(order), (names, order)
-    return {n: torch.from_numpy(fx[f"noise{i}_{k}"]) for i, (n, k) in enumerate(zip(names, order))}
 
 
 def oracle_setup(fx):

@@ -15,8 +15,11 @@ class _Objects(list):
     z_near, z_far, lindisp = 1.25, 2.75, False
 
 
-def _make_dataset(net32, rend, n_obj, NV, W, H, focal):
+def _make_dataset(net32, rend, n_obj, NV, W, H, focal, seed=777):
+    """Ground truth = this package's fp32-path render of every target view with the jitter evaluate(seed=seed) will draw for
+    that (object, view): evalio keys the per-view seed by frame_seed(frame_seed(seed, object), view)."""
     import golden_util as gu
+    from pixel_nerf_multiscale_amd.parallel import frame_seed
     data = _Objects()
     for o in range(n_obj):
         poses = torch.from_numpy(np.stack([gu.pose_spherical(40.0 * v + 13.0 * o, -20.0 - 3.0 * o, 2.0) for v in range(NV)]))
@@ -25,11 +28,12 @@ def _make_dataset(net32, rend, n_obj, NV, W, H, focal):
         images = torch.zeros(NV, 3, H, W)                                       # trunk sees it
         images[0] = src_img[0]
         net32.encode(src_img.cuda()[None], poses[:1].cuda()[None], torch.tensor(focal)[None].cuda())
-        rend.forced_seed = 777                                                  # the same jitter in ground truth and evaluation
         for v in range(1, NV):
+            rend.forced_seed = frame_seed(frame_seed(seed, o), v)               # the same jitter in ground truth and evaluation
             rgb, _ = rend.render_image(net32, poses[v], W, H, focal, data.z_near, data.z_far)
             images[v] = (rgb.clamp(0, 1).permute(2, 0, 1) * 2 - 1).cpu()
         data.append(dict(path=f"/data/cat{o % 2}/obj{o:03d}", images=images, poses=poses, focal=focal))
+    rend.forced_seed = None
     return data
 
 
@@ -50,7 +54,7 @@ def test_evaluate_two_objects_resume_and_lut(tmp_path):
 
     # pass 1: only the first object (max_objects = 1), fixed source view "0", fp16 kernel
     net.precision = "fp16"
-    m1 = evalio.evaluate(net, rend, data, out, source="0", max_objects=1, verbose=False)
+    m1 = evalio.evaluate(net, rend, data, out, source="0", max_objects=1, verbose=False, seed=777)
     lines = open(os.path.join(out, "finish.txt")).read().split("\n")
     assert len([x for x in lines if x]) == 1 and lines[0].split()[0] == "obj000" and lines[0].split()[3] == "1"
     assert m1[2] == 1 and 45.0 <= m1[0] < 99.0 and 0.99 <= m1[1] <= 1.0            # fp16 render vs fp32 ground truth
@@ -70,7 +74,7 @@ def test_evaluate_two_objects_resume_and_lut(tmp_path):
         rendered.append(res[0].detach().clone())
         return res
     rend.render_image = recording
-    m2 = evalio.evaluate(net, rend, data, out, viewlist=str(lut), verbose=False)
+    m2 = evalio.evaluate(net, rend, data, out, viewlist=str(lut), verbose=False, seed=777)
     rend.render_image = orig
     rows = [x.split() for x in open(os.path.join(out, "finish.txt")).read().split("\n") if x]
     assert [r[0] for r in rows] == ["obj000", "obj001"] and len(calls) == NV - 1   # only object 1 was rendered
@@ -82,7 +86,7 @@ def test_evaluate_two_objects_resume_and_lut(tmp_path):
     # pass 3: everything finished -> nothing rendered, same means; eval view list + include_src + multicat names
     calls.clear()
     rend.render_image = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    m3 = evalio.evaluate(net, rend, data, out, source="0", verbose=False)
+    m3 = evalio.evaluate(net, rend, data, out, source="0", verbose=False, seed=777)
     assert not calls and m3 == m2
     out2 = str(tmp_path / "eval_out2")
     m4 = evalio.evaluate(net, rend, data, out2, source="0", eval_view_list=[0, 2], include_src=True, multicat=True,

@@ -217,9 +217,16 @@ def _psnr(a, b):
 #   fp16: >= 50 dB — SURVEY §8(c)'s adopted bound holds end to end as well (measured minimum 54 dB);
 #   bf16: >= 40 dB — BELOW the §8(c) bound, bf16 only: a reported sanity floor under the measured spread (41.9 dB minimum),
 #         not a precision claim; bf16 is the dtype BASELINE.json names for cfg 2, fp16 is what precision="auto" selects.
+# Round 4: ONE 16-bit dtype carries both the headline rate and the parity claim — fp16 (bench.HEADLINE_DTYPE, what
+# precision="auto" selects).  Its floors are SURVEY §8(c)'s bound or tighter on every test of this suite
+# (tests/test_host_cpu.py::test_headline_dtype_is_held_to_survey_8c checks exactly that on the CPU).  bf16 stays a
+# supported, benchmarked secondary format with the floors below, labelled NON-CONFORMING: it does not meet §8(c) on
+# every shape and nothing in the bench's headline is quoted on it.
+SURVEY_8C_DB = 50.0
 BF16_FLOOR_DB, FP16_FLOOR_DB = 42.4, 58.0
 FLOOR_DB = {"bf16": BF16_FLOOR_DB, "fp16": FP16_FLOOR_DB}
 FINE_E2E_FLOOR_DB = {"bf16": 40.0, "fp16": 50.0}
+NON_CONFORMING_DTYPES = ("bf16",)
 
 
 @pytest.mark.parametrize("prec,floor_pts,floor_px", [("bf16", 52.0, BF16_FLOOR_DB), ("fp16", 68.0, FP16_FLOOR_DB)])

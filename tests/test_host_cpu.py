@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.PROTOTYPES), declared ^ set(N.PROTOTYPES)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.pnr_version() == 101
+    assert N.lib.pnr_version() == 102
     assert N.lib.pnr_error_string(-4).decode() == "workspace too small"
 
 
@@ -229,3 +229,19 @@ def test_tile_gemm_grid_is_a_bijection_and_xcd_local(M, N, Rn, rows, split):
         assert len({b % 8 for b in blocks}) == 1                                   # one XCD
         slots = sorted(b // 8 for b in blocks)
         assert slots == list(range(slots[0], slots[0] + len(slots)))              # consecutive slots of that XCD
+
+
+def test_headline_dtype_is_held_to_survey_8c():
+    """a 16-bit render is >= 50 dB from the fp32 path on every synthetic config.  The dtype bench.py quotes its
+    headline on must be the dtype the GPU suite holds to that bound (coarse pass, injected fine positions, fine end to end);
+    any other 16-bit format is labelled non-conforming there and appears in the bench as a secondary row only."""
+    import bench
+    import test_gpu_parity as tp
+    h = bench.HEADLINE_DTYPE
+    assert h == "fp16" and h not in tp.NON_CONFORMING_DTYPES
+    assert bench.PSNR_BOUND_8C_DB == tp.SURVEY_8C_DB == 50.0
+    assert tp.FLOOR_DB[h] >= tp.SURVEY_8C_DB and tp.FINE_E2E_FLOOR_DB[h] >= tp.SURVEY_8C_DB
+    assert bench.SECONDARY[0] == (bench.DEFAULT, "bf16")          # the other 16-bit format stays visible beside the headline
+    # every BASELINE shape is benchmarked in the headline dtype
+    for wl in bench.WORKLOADS:
+        assert wl == bench.DEFAULT or (wl, h) in bench.SECONDARY, wl

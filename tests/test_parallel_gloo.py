@@ -44,7 +44,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10), (2, 1)])
+# world 8 = the node the scaling bench runs on: BASELINE cfg 4's 120 000-ray DTU frame (15 000 rays per rank), and fewer rays
+# than ranks (three ranks render nothing and still take part in the collective)
+@pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10), (2, 1), (8, 120000), (8, 5)])
 def test_sharded_equals_unsharded(world, B):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

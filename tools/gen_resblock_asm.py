@@ -58,6 +58,7 @@ import re
 
 # timing experiments only (results are garbage): nobarrier, nodma, nowait, nosnap, dma1, dmaearly, dmaplain, dmaquarter, nodsread,
 # nolgkm, noadvance; placement: align4; cache policy of the weight stream (results stay exact): nt0 .. nt3;
+# fp16 saturation by v_pk_min instead of MODE.FP16_OVFL (round-3 form): satmin;
 # hazard experiments of round 2 (kept for the record, all explained by rule R1): fullwait, ldswait, nosat, cvtnop, drainA/B/C, waitA4, sleepA, barA
 DIAG = os.environ.get("PNR_ASM_DIAG", "")
 # pieces q >= NT_FROM of every stage carry the non-temporal hint (nt0 = all .. nt3 = a quarter of the stream; default: none)
@@ -143,8 +144,11 @@ class Emit:
         if "cvtnop" in DIAG:
             self.e("s_nop 1")
         self.e(f"v_pk_max_i16 v{dst}, v{dst}, 0")
-        if self.dt == "f16":
-            self.e(f"v_pk_min_i16 v{dst}, v{dst}, s38")          # saturate +inf/NaN to 65504
+        # fp16: no saturating v_pk_min here — the kernel runs with MODE.FP16_OVFL set (k_point_mfma's entry), under which the
+        # conversion itself clamps an overflowing finite value to +-65504 (measured on gfx950 for v_cvt_pk_f16_f32:
+        # tools/dev/ubench/ovfl_ubench.hip, profiles/r04_fp16_ovfl.txt; -2.3 % kernel time on the headline frame)
+        if self.dt == "f16" and "satmin" in DIAG:                # the round-3 form, for A/B runs
+            self.e(f"v_pk_min_i16 v{dst}, v{dst}, s38")
 
     def snapshot_ks(self, ks):
         """relu(x) of row groups 2ks, 2ks+1 -> the two B fragments of k-step ks (16 accumulator reads, 8 packs)."""
@@ -173,14 +177,28 @@ class Emit:
         e("s_cselect_b32 s29, s27, s26")
         e("2:")
 
-    def stage(self, mm, rd_cur, rd_nxt, m0_sreg, hooks=None):
+    def stage(self, mm, rd_cur, rd_nxt, m0_sreg, hooks=None, vm_alt=None):
         """One stage: 16 fragments, fragment f in A(f & 7).  mm(f) -> the two MFMA lines of fragment f.  rd_cur / rd_nxt:
         VGPRs holding this lane's read base of this stage's / the next stage's ring slot; m0_sreg: SGPR with the LDS-DMA
         destination of the stage being loaded meanwhile.  The refill of A(f & 7) (fragment f + 8) is issued one MFMA late
         (after the first MFMA of fragment f + 1) and the 4 DMA pieces after the second MFMA of fragments 1, 5, 9, 13, so
-        no MFMA gap carries more than one of them.  hooks: {f: callable} extra work after fragment f's second MFMA."""
+        no MFMA gap carries more than one of them.  hooks: {f: callable} extra work after fragment f's second MFMA.
+        vm_alt = (flag test, N): where the run-time flag is set, extra LDS-DMA pieces (younger than the pieces this stage must
+        see landed) are in flight, and the counted wait is vmcnt(N) instead of vmcnt(4) — loads retire in order."""
         e = self.e
-        e("s_waitcnt vmcnt(4)")
+        if vm_alt and "nodma" not in DIAG and "nowait" not in DIAG:
+            test, n = vm_alt
+            self.uid = getattr(self, "uid", 100) + 1
+            e(test)
+            e(f"s_cbranch_scc1 {self.uid}f")
+            e("s_waitcnt vmcnt(4)")
+            e(f"s_branch {self.uid + 1}f")
+            e(f"{self.uid}:")
+            e(f"s_waitcnt vmcnt({n})")
+            self.uid += 1
+            e(f"{self.uid}:")
+        else:
+            e("s_waitcnt vmcnt(4)")
         e("s_barrier")
         pend = None
         if "dmaearly" in DIAG:
@@ -278,8 +296,8 @@ def fixed_bases(E, ring_lane, ring_wave):
         e(f"s_add_u32 s{40 + k}, s35, {ring_wave}")
 
 
-def fixed_stage(E, i, mm, hooks=None):
-    E.stage(mm, f"v{10 + (i & 3)}", f"v{10 + ((i + 1) & 3)}", f"s{40 + (i & 3)}", hooks)
+def fixed_stage(E, i, mm, hooks=None, vm_alt=None):
+    E.stage(mm, f"v{10 + (i & 3)}", f"v{10 + ((i + 1) & 3)}", f"s{40 + (i & 3)}", hooks, vm_alt)
 
 
 def xstages_core(E, baddr, cfg2, ring_lane, ring_wave, dma_off, bias_dword, allow_init=False):
@@ -408,7 +426,7 @@ def gen_xstages(dt):
     return E.L
 
 
-def bias_kstep_with_snapshot(E, i0):
+def bias_kstep_with_snapshot(E, i0, extra0=None, extra1=None, vm_alt1=None):
     """The block's head k-step (the bias k-step, or with the fold the last lin_z k-step) as stages i0, i0+1 of the fixed part
     (B = v16-23), carrying the snapshot relu(x) -> XB just in time: a row group is final once ITS fragment of this k-step has
     run (fragment f of the first stage = row group f, of the second = row group 16 + f), so k-step ks of the snapshot (row
@@ -422,8 +440,14 @@ def bias_kstep_with_snapshot(E, i0):
             return [f"{E.mfma} {X(rg, cg)}, {A(f & 7)}, {BX(cg)}, {X(rg, cg)}" for cg in range(2)]
         return mm
     snap = lambda ks: (lambda: E.snapshot_ks(ks))
-    fixed_stage(E, i0, mm_half(0), {3: snap(0), 5: snap(1), 7: snap(2), 9: snap(3), 11: snap(4)})
-    fixed_stage(E, i0 + 1, mm_half(1), {0: snap(5), 1: snap(6), 2: snap(7), 4: snap(8), 6: snap(9), 8: snap(10)})
+    h0 = {3: snap(0), 5: snap(1), 7: snap(2), 9: snap(3), 11: snap(4)}
+    h1 = {0: snap(5), 1: snap(6), 2: snap(7), 4: snap(8), 6: snap(9), 8: snap(10)}
+    if extra0:
+        h0.update(extra0)           # (the resblock's image prefetch rides in fragment 14 of both stages)
+    if extra1:
+        h1.update(extra1)
+    fixed_stage(E, i0, mm_half(0), h0)
+    fixed_stage(E, i0 + 1, mm_half(1), h1, vm_alt1)
 
 
 def tail_snapshot_hooks(E):
@@ -437,8 +461,15 @@ def gen(dt):
     lane*16 (v), %25 DMA lane offset (v), %26 LDS address of fc_0.bias[block] + 16*(lane>>4) (v), %27 bias B dword 0 (v),
     %28 lin_z B image address + lane*16 (v), %29 = lin_z k-steps of a prefixed block that run as x-stages | number of
     consecutive blocks with the lin_z prefix << 16 | number of blocks without it after them << 20 | bias folded into the last
-    lin_z k-step << 24 (%26 names the FIRST block's bias rows; the two stages at the head of the fixed part are the bias k-step,
-    or with the fold the last lin_z k-step).
+    lin_z k-step << 24 | image prefetch << 25 (%26 names the FIRST block's bias rows; the two stages at the head of the fixed part
+    are the bias k-step, or with the fold the last lin_z k-step).
+    Image prefetch (bit 25; blocks with several lin_z parts — multi-scale — run one block per statement): the NEXT block's first
+    gathered lin_z image (16 KiB, kept in the wave's workspace by the view's first block) is fetched back into the wave's B-image
+    buffer by 16 LDS-DMA pieces riding in fragment 14 of the two head stages — the buffer is free from there on (the prefix's
+    reads are drained, the head k-step's B pair is in registers) and the next reader is the x-stages statement after this one,
+    behind its entry wait.  %30 = the image's address in the workspace (s64), %31 = lane*16 (v), %32 = LDS address of the
+    buffer (s).  The pieces are younger than weight pieces the next three stages wait for: those stages' counted waits are
+    vmcnt(12 / 20 / 12) where the bit is set.
     Stage order (k_pack_mlp follows it): [lin_z k-steps x 2] | bias x 2 | F(0) | F(1) G(0) | ... | F(15) G(14) | G(15), with
     F(c) = the 2 fc_0 stages of chunk c (chunk accumulator += W0[32c..32c+31, :] . relu(x)) and G(c) = its 2 fc_1 stages
     (x += W1[:, 32c..32c+31] . relu(h_c)).  Two chunk accumulators alternate (v40-55 / v72-87): while F(c+1) runs on one, the
@@ -503,7 +534,33 @@ def gen(dt):
     hbias(ACC[0], "h")                                       # chunk 0
     E.read_first_frags("v10")
     # ---------------------------------------------------------------- bias k-step + snapshot
-    bias_kstep_with_snapshot(E, 0)
+    PF = "s_bitcmp1_b32 %29, 25"
+
+    def prefetch_half(half):
+        """8 pieces = 8 KiB of the next block's image: source %30 + 8192 half + 4096 j, destination %32 + the same."""
+        def hook():
+            E.uid = getattr(E, "uid", 100) + 1
+            lab = E.uid
+            e(PF)
+            e(f"s_cbranch_scc0 {lab}f")
+            for j in range(2):
+                off = 8192 * half + 4096 * j
+                e("s_mov_b64 s[34:35], %30")                 # s34 / s35: free here (loop counter / loader temp of other phases)
+                if off:
+                    e(f"s_add_u32 s34, s34, {off}")
+                    e("s_addc_u32 s35, s35, 0")
+                e(f"s_add_u32 m0, %32, {off}")
+                e("s_nop 0")
+                for q in range(4):
+                    e("global_load_lds_dwordx4 %31, s[34:35]" + (f" offset:{q * 1024}" if q else "") + " sc1")
+            e(f"{lab}:")
+        return hook
+    if "noprefetch" in DIAG:
+        bias_kstep_with_snapshot(E, 0)
+        alt = [None, None]
+    else:
+        bias_kstep_with_snapshot(E, 0, {14: prefetch_half(0)}, {14: prefetch_half(1)}, (PF, 12))
+        alt = [(PF, 20), (PF, 12)]
 
     def mm_fc0(acc, half):
         def mm(f):
@@ -530,11 +587,11 @@ def gen(dt):
             hooks[15] = lambda: hbias(acc, "h")
         return hooks
 
-    def F(acc, i, hooks0=None, need_bias=True):
+    def F(acc, i, hooks0=None, need_bias=True, vm_alts=(None, None)):
         if need_bias:
             E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
-        fixed_stage(E, i, mm_fc0(acc, 0), hooks0)
-        fixed_stage(E, i + 1, mm_fc0(acc, 1))
+        fixed_stage(E, i, mm_fc0(acc, 0), hooks0, vm_alts[0])
+        fixed_stage(E, i + 1, mm_fc0(acc, 1), None, vm_alts[1])
 
     def G(i):
         fixed_stage(E, i, mm_fc1(0))
@@ -543,7 +600,7 @@ def gen(dt):
     # chunk 1's fc_0.bias rows into the second accumulator, then F(0) with the last five k-steps of the snapshot in its first stage
     hbias(ACC[1], "g")
     E.need([f"h{rgl}{cg}" for rgl in range(2) for cg in range(2)])
-    F(ACC[0], 2, tail_snapshot_hooks(E), need_bias=False)
+    F(ACC[0], 2, tail_snapshot_hooks(E), need_bias=False, vm_alts=alt)
     # the loop head: outstanding = [g-bias reads?]  make the state explicit: the g reads are waited for here
     E.need([f"g{rgl}{cg}" for rgl in range(2) for cg in range(2)])
     if "drainC" in DIAG:
@@ -629,7 +686,7 @@ def gen_viewspill(dt):
     (even, odd) pairs (the reduce reads the same mapping back).  Half the bytes of an fp32 park: with every CU parking at the
     same moment the stores queue on the fabric (13.4 k cycles per park with 256 workgroups against 4.7 k with 32,
     profiles/r03_park_contention.txt), so bytes are time.  The rounding is the one every layer's input already takes (the
-    next reader of x is relu -> 16-bit for fc_0); fp16 saturates at +-65504 like the activations.
+    next reader of x is relu -> 16-bit for fc_0); fp16 saturates at +-65504 like the activations (MODE.FP16_OVFL).
     Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v).  Writes v68-71 / v96-223 (rule R1: entry guard)."""
     E = Emit(dt)
     e = E.e
@@ -648,7 +705,7 @@ def gen_viewspill(dt):
                 e(f"v_accvgpr_read_b32 v{68 + 2 * (i & 1)}, a{a0}")
                 e(f"v_accvgpr_read_b32 v{69 + 2 * (i & 1)}, a{a0 + 1}")
                 e(f"{E.cvt} v{buf + i}, v{68 + 2 * (i & 1)}, v{69 + 2 * (i & 1)}")
-                if dt == "f16":
+                if dt == "f16" and "satmin" in DIAG:             # round-3 form; MODE.FP16_OVFL clamps in the conversion now
                     e(f"v_pk_min_f16 v{buf + i}, v{buf + i}, s38")
                     e(f"v_pk_max_f16 v{buf + i}, v{buf + i}, s35")
             e(f"global_store_dwordx4 %17, v[{buf}:{buf + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else "") + PARK_POLICY)
@@ -779,7 +836,7 @@ def audit_statement(name, lines):
         if l.startswith("global_load_lds"):
             # the nearest M0 write above it must be >= 1 wait state away
             for k in range(i - 1, -1, -1):
-                if lines[k].startswith("s_mov_b32 m0"):
+                if lines[k].startswith(("s_mov_b32 m0", "s_add_u32 m0")):
                     assert k <= i - 2, f"{name}: R3 — no wait state between '{lines[k]}' and the DMA"
                     break
                 if lines[k].startswith("global_load_lds") or lines[k].endswith(":"):
