@@ -728,30 +728,79 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
     }
 }
 
-// dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4): one thread per k
-// column walks a slice of the rows (X read once, coalesced; dY rows broadcast).  HBM-bound: 4 K bytes per row.
+// dW (4, K) += dY(M,4)^T act(X(M,K)),  db (4) += column sums of dY — the output head (d_out = 4).  HBM-bound: 4 K bytes per
+// row.  A block owns one row slice x 128 columns: thread (cq = t & 31, rl = t >> 5) takes the float4 of columns 4 cq .. + 3 of
+// rows rl, rl + 8, .. of the slice (a wave reads two 512-B row segments per instruction), eight loads in flight; the eight
+// row lanes are summed through LDS in a fixed order (bit-reproducible).  Round 3's form — one thread per column walking the
+// whole slice, 2 x 64 blocks — was latency-bound at 0.35 TB/s (248 us per 49152 x 512 call).
 template <bool RELU_X>
 static __global__ void __launch_bounds__(256) k_grad_w_head(const float4* __restrict__ dY, const float* __restrict__ X,
                                                             int ldx, float* __restrict__ dW, int ldw,
                                                             float* __restrict__ db, int M, int K, int rows_per_split,
                                                             size_t zs_w, size_t zs_b) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][4][132];                       // [row lane][output row][column] (+4 pad)
+    __shared__ float redb[8][4];
+    const int t = threadIdx.x, cq = t & 31, rl = t >> 5;
+    const int k = blockIdx.x * 128 + 4 * cq;
     dW += blockIdx.y * zs_w;
     if (db) db += blockIdx.y * zs_b;
     const int mb = blockIdx.y * rows_per_split, me = min(M, mb + rows_per_split);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    const bool live = k < K;
-    for (int m = mb; m < me; ++m) {
-        float4 g = dY[m];
-        float x = live ? X[(size_t)m * ldx + k] : 0.f;
-        if (RELU_X) x = fmaxf(x, 0.f);
-        a0 = fmaf(g.x, x, a0); a1 = fmaf(g.y, x, a1); a2 = fmaf(g.z, x, a2); a3 = fmaf(g.w, x, a3);
+    float a[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[o][c] = 0.f;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    const bool vec = k + 3 < K && (ldx & 3) == 0 && (((uintptr_t)X) & 15) == 0;
+    auto row = [&](int m, float4& x, float4& g) {
+        g = dY[m];
+        if (vec) x = *(const float4*)(X + (size_t)m * ldx + k);
+        else {
+            const float* xr = X + (size_t)m * ldx;
+            x = make_float4(k < K ? xr[k] : 0.f, k + 1 < K ? xr[k + 1] : 0.f, k + 2 < K ? xr[k + 2] : 0.f, k + 3 < K ? xr[k + 3] : 0.f);
+        }
+    };
+    auto acc = [&](float4 x, const float4& g) {
+        if (RELU_X) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[o][c] = fmaf(gv[o], xv[c], a[o][c]);
         b0 += g.x; b1 += g.y; b2 += g.z; b3 += g.w;
+    };
+    int m = mb + rl;
+    for (; m + 56 < me; m += 64) {                          // eight rows of this row lane in flight
+        float4 x[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row(m + 8 * u, x[u], g[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc(x[u], g[u]);
     }
-    if (live) {
-        dW[k] = a0; dW[ldw + k] = a1; dW[2 * ldw + k] = a2; dW[3 * ldw + k] = a3;
+    for (; m < me; m += 8) {
+        float4 x, g;
+        row(m, x, g);
+        acc(x, g);
     }
-    if (db && k == 0) { db[0] = b0; db[1] = b1; db[2] = b2; db[3] = b3; }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[rl][o][4 * cq + c] = a[o][c];
+    if (cq == 0) { redb[rl][0] = b0; redb[rl][1] = b1; redb[rl][2] = b2; redb[rl][3] = b3; }
+    __syncthreads();
+    for (int e = t; e < 4 * 128; e += 256) {                 // (output row o, column c): the eight row lanes in order
+        const int o = e >> 7, c = e & 127;
+        float sum = red[0][o][c];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) sum += red[r][o][c];
+        if (blockIdx.x * 128 + c < K) dW[(size_t)o * ldw + blockIdx.x * 128 + c] = sum;
+    }
+    if (db && blockIdx.x == 0 && t < 4) {
+        float sum = redb[0][t];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) sum += redb[r][t];
+        db[t] = sum;
+    }
 }
 
 // d(pre-activation) of the output head: rgb = sigmoid(o) -> y(1-y); sigma = relu(o) -> [y > 0]
@@ -1241,6 +1290,17 @@ __global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restr
     db[n] = acc;
 }
 
+// the same over the gradient stream's bf16 copy (what the GEMM path's row sums of the staged tile add up)
+__global__ void k_col_sums16(const uint16_t* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows, size_t zs_b) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    db += blockIdx.y * zs_b;
+    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += __builtin_bit_cast(float, (uint32_t)dY[(size_t)m * ldy + n] << 16);
+    db[n] = acc;
+}
+
 // y (+)= act(x) W^T + b on the fp32 MFMA tile kernel, for the fp32 inference path (point_f32.hip): the same GEMM the taped
 // training forward uses.  W (N, K) row-major as nn.Linear stores it; accum adds to what Y holds.
 int32_t linear_f32_mfma(const float* X, int ldx, const float* W, int ldw, const float* b, bool relu_in, bool accum, float* Y,
@@ -1265,7 +1325,8 @@ __global__ void k_reduce_parts(const float* __restrict__ part, int nz, size_t zs
 // request takes k_col_sums.
 template <bool RELU_X>
 static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int64_t M,
-                      int N, int K, hipStream_t s, int half, const DetWs& ws, const uint16_t* X16 = nullptr) {
+                      int N, int K, hipStream_t s, int half, const DetWs& ws, const uint16_t* X16 = nullptr,
+                      const uint16_t* dY16 = nullptr /* the gradient stream's bf16 copy (with X16): read instead of dY */) {
     if ((!dW && !db) || M == 0) return PNR_OK;
     const size_t zs_w = (size_t)N * K, zs_b = (size_t)N;
     // rows per split: the kernel's natural slice, enlarged until the splits fit the scratch
@@ -1301,13 +1362,15 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     if (!dW) {
         nz = splits_for(2048, &rows);
         float* pb = pw + (size_t)nz * zs_w;
-        hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)nz), dim3(256), 0, s, dY, ldy, pb, (int)M, N, rows, zs_b);
+        if (dY16) hipLaunchKernelGGL(k_col_sums16, dim3((N + 255) / 256, (unsigned)nz), dim3(256), 0, s, dY16, ldy, pb, (int)M, N, rows, zs_b);
+        else hipLaunchKernelGGL(k_col_sums, dim3((N + 255) / 256, (unsigned)nz), dim3(256), 0, s, dY, ldy, pb, (int)M, N, rows, zs_b);
         PNR_LAUNCH_CHECK();
         return finish(nz);
     }
     const bool mfma_shape = N >= 32 && K >= 32;
-    const bool use_half = half && mfma_shape && N % 4 == 0 && K % 4 == 0 && al16(dY, ldy) && (X16 ? true : al16(X, ldx));
+    const bool use_half = half && mfma_shape && N % 4 == 0 && K % 4 == 0 && (dY16 ? ldy % 8 == 0 : al16(dY, ldy)) && (X16 ? true : al16(X, ldx));
     if (X16 && !(use_half && half == 1)) return PNR_E_UNSUPPORTED;      // the 16-bit tape is read by the bf16 MFMA kernel only
+    if (dY16 && !X16) return PNR_E_UNSUPPORTED;
     const bool head = !mfma_shape && N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0;
     nz = splits_for(mfma_shape ? 1024 : head ? 256 : 2048, &rows);
     float* pb = pw + (size_t)nz * zs_w;
@@ -1319,6 +1382,10 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
             hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
+        else if (use_half && X16 && dY16)
+            hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, true, true, false>), grid, dim3(256), 0, s,
+                               (const void*)dY16, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
+                               (const void*)nullptr, 0, pw, K, pbk, N, K, (int)M, rows, zs_w, zs_b);
         else if (use_half && X16)
             hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, false, true, false>), grid, dim3(256), 0, s,
                                (const void*)dY, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
@@ -1332,7 +1399,7 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, vec_flags(dY, ldy, X, ldx), zs_w, zs_b);
     } else if (head) {
-        dim3 grid((K + 255) / 256, (unsigned)nz);
+        dim3 grid((K + 127) / 128, (unsigned)nz);
         hipLaunchKernelGGL((k_grad_w_head<RELU_X>), grid, dim3(256), 0, s, (const float4*)dY, X, ldx, pw, K, pbk, (int)M, K, rows,
                            zs_w, zs_b);
     } else {
@@ -1496,14 +1563,28 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s, half, dws)));
     PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s, half)));
     bool dz_started = false;
+    // 16-bit tape: the fp32 dh buffer holds the two bf16 streams instead (dh, and the copy of dx)
+    uint16_t* dh16 = (uint16_t*)dh;
+    uint16_t* dx16 = dh16 + (size_t)MV * H;
+    bool dx16_valid = false;
+    auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
+        hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    };
     for (int b = nb - 1; b >= 0; --b) {
         const int64_t M = t.rows[b];
-        if (t16) {      // the same four GEMMs, the tape operands / masks read as the bf16 the fp32-tape form would round them to
-            PNR_TRY((grad_w<true>(dx, H, nullptr, H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws, t.h16p[b])));
-            PNR_TRY((gemm16<false, true>(G16{nullptr, t.h16p[b], nullptr}, dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, nullptr, H,
-                                         dh, H, M, H, H, s)));
-            PNR_TRY((grad_w<true>(dh, H, nullptr, H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws, t.A16[b])));
-            PNR_TRY((gemm16<false, true>(G16{nullptr, t.A16[b], nullptr}, dh, H, mlp->fc0_w[b], H, nullptr, dx, H, nullptr, H, dx, H,
+        if (t16) {
+            // the same four GEMMs, every operand read as the bf16 the fp32-tape form would round it to: the tape operands /
+            // masks, and (round 4) the gradient stream — dh exists as bf16 only (its two readers stage it as bf16 anyway), dx
+            // keeps its fp32 form for the residual sum and gets a bf16 copy from the epilogue that produces it.  Same roundings
+            // of the same values: gradients stay bit-identical to the fp32-tape form; 0.76x the bytes of a block's backward.
+            if (!dx16_valid) { PNR_TRY(to16(dx, M * H, dx16)); dx16_valid = true; }
+            PNR_TRY((grad_w<true>(dx, H, nullptr, H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws, t.h16p[b], dx16)));
+            PNR_TRY((gemm16<false, true>(G16{dx16, t.h16p[b], dh16}, nullptr, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, nullptr, H,
+                                         nullptr, H, M, H, H, s)));
+            PNR_TRY((grad_w<true>(nullptr, H, nullptr, H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws, t.A16[b], dh16)));
+            PNR_TRY((gemm16<false, true>(G16{dh16, t.A16[b], dx16}, nullptr, H, mlp->fc0_w[b], H, nullptr, dx, H, nullptr, H, dx, H,
                                          M, H, H, s)));
         } else {
         PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws)));
@@ -1525,6 +1606,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                                per_view, mlp->combine_type, dx2);
             PNR_LAUNCH_CHECK();
             float* tmp = dx; dx = dx2; dx2 = tmp;
+            dx16_valid = false;         // (P rows became NS P rows of another buffer)
         }
     }
     PNR_TRY((grad_w<false>(dx, H, t.zx + L, E, gr->lin_in_w, Din, gr->lin_in_b, MV, H, Din, s, half, dws)));

@@ -7,7 +7,7 @@ import torch
 import bench
 from pixel_nerf_multiscale_amd import _native as N
 wl = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
-spec, net, rend, rays = bench.build(wl, "bf16", torch.device("cuda"))
+spec, net, rend, rays = bench.build(wl, os.environ.get("PNR_STAMPS_PRECISION", bench.HEADLINE_DTYPE), torch.device("cuda"))
 if len(sys.argv) > 2:          # fewer rays: fewer workgroups active at once (how much of a section is contention between CUs?)
     rays = rays[:, :int(sys.argv[2])].contiguous()
 fn = N.lib._cdll.pnr_debug_stamps
