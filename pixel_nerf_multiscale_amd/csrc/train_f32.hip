@@ -841,7 +841,43 @@ static __global__ void k_combine_bwd(const float* __restrict__ g, const float* _
 //   d_latent[level][view][c][tap] += dzx[row][c] * w_tap                       (encoder.py:182,198 grid_sample)
 //   d(point) through the projection (backup2:215-221) and the positional code (code.py:30-46)
 // dzx rows are view-major (row = v*P + g).  d_lat entries may be NULL (encoder frozen); d_xyz / d_z may be NULL.
-struct LatGrad { float* p[PNR_MAX_LEVELS]; };
+// p: the caller's d_latent maps (fp32, NCHW).  q (round 4; maps beyond the LDS path): per level a 64-bit FIXED-POINT copy of
+// the same map in the backward workspace that the taps are summed into with integer atomics — integer addition commutes, so
+// the sum does not depend on the order the contributions arrive in: the latent gradient of DTU-sized and multi-scale maps is
+// bit-reproducible from run to run like every other gradient.  scale_bits: the map's common binary exponent (k_latq_scale).
+struct LatGrad { float* p[PNR_MAX_LEVELS]; long long* q[PNR_MAX_LEVELS]; const int* scale_bits; };
+
+// max |dzx[:, :L]| as float bits (atomicMax on the bits of a non-negative float is an order-independent integer maximum)
+static __global__ void __launch_bounds__(256) k_abs_max_cols(const float* __restrict__ x, int64_t rows, int ld, int L, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const int64_t n = rows * L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / L;
+        const float v = fabsf(x[r * ld + (i - r * L)]);
+        m = (v == v) ? fmaxf(m, v) : m;                       // a NaN would poison the bit comparison: it goes to the map anyway
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+// The fixed-point scale 2^s of the maps: every contribution is |g w| <= max|g| < 2^ex and a map entry sums at most n_terms of
+// them, so with s = 61 - ex - ceil(log2(n_terms)) no partial sum can leave the int64 range, and the resolution 2^-s is
+// ~2^-40 of the largest gradient element (fp32 atomics resolve 2^-24 of the running sum).
+static __global__ void k_latq_scale(const unsigned* __restrict__ max_bits, long long n_terms, int* __restrict__ scale_bits) {
+    const float mx = __uint_as_float(*max_bits);
+    int ex = 0;
+    if (mx > 0.f) (void)frexpf(mx, &ex);                      // mx < 2^ex
+    int lg = 0;
+    while ((1ll << lg) < n_terms && lg < 62) ++lg;
+    int sb = 61 - ex - lg;
+    sb = sb > 1000 ? 1000 : sb < -1000 ? -1000 : sb;
+    *scale_bits = sb;
+}
+// d_latent += fixed-point map * 2^-s
+static __global__ void k_latq_finalize(const long long* __restrict__ q, int64_t n, const int* __restrict__ scale_bits, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] += (float)ldexp((double)q[i], -*scale_bits);
+}
 
 static __global__ void __launch_bounds__(256) k_features_bwd(
     pnr_views vw, PointSrc src, int64_t P, int64_t pts_per_obj, int L, int d_in, int use_code_viewdirs,
@@ -874,9 +910,18 @@ static __global__ void __launch_bounds__(256) k_features_bwd(
                 float gz = drow[c0 + ch];
                 size_t base = ((size_t)view * C + ch) * (size_t)(H * W);
                 if (dl.p[lvl]) {
+                    if (dl.q[lvl]) {          // order-independent: 64-bit fixed-point integer atomics (see LatGrad)
+                        const double sc = ldexp(1.0, *dl.scale_bits);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (t.w[i] != 0.f) atomicAdd(dl.p[lvl] + base + t.off[i], gz * t.w[i]);
+                        for (int i = 0; i < 4; ++i)
+                            if (t.w[i] != 0.f)
+                                atomicAdd((unsigned long long*)(dl.q[lvl] + base + t.off[i]),
+                                          (unsigned long long)__double2ll_rn((double)(gz * t.w[i]) * sc));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (t.w[i] != 0.f) atomicAdd(dl.p[lvl] + base + t.off[i], gz * t.w[i]);
+                    }
                 }
                 if (want_p) {
                     const float* lb = vw.latent[lvl] + base;
@@ -1202,10 +1247,18 @@ static uint64_t latent_part_bytes(const pnr_views* vw, int64_t P) {
     return nbx * vw->n_objs * vw->n_views * (uint64_t)vw->lat_c[0] * vw->lat_h[0] * vw->lat_w[0] * 4;
 }
 
+// maps that take the fixed-point route (everything the LDS path does not serve): 8 bytes per map element + the scale words
+static uint64_t latent_q_bytes(const pnr_views* vw) {
+    if (latent_grad_in_lds(vw)) return 0;
+    uint64_t n = 0;
+    for (int l = 0; l < vw->n_levels; ++l)
+        n += (uint64_t)vw->n_objs * vw->n_views * vw->lat_c[l] * vw->lat_h[l] * vw->lat_w[l];
+    return n * 8 + 256;
+}
 uint64_t train_bwd_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw, int64_t P) {
     const uint64_t NS = vw->n_views, H = mlp->d_hidden, E = (mlp->d_latent + mlp->d_in + 3) & ~3;
     return a256(NS * P * H * 4) * 3 + a256(NS * P * E * 4) + a256((uint64_t)P * 16) + a256(det_ws_floats(mlp) * 4) +
-           a256(latent_part_bytes(vw, P)) + 256;
+           a256(latent_part_bytes(vw, P)) + a256(latent_q_bytes(vw)) + 256;
 }
 
 static inline int vec_flags(const float* A, int lda, const float* B, int ldb) {
@@ -1550,7 +1603,8 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* dzx = (float*)wp;               wp += a256((uint64_t)MV * E * 4);
     float* do4 = (float*)wp;               wp += a256((uint64_t)P * 16);
     const DetWs dws{(float*)wp, det_ws_floats(mlp)};  wp += a256(det_ws_floats(mlp) * 4);
-    float* lat_part = (float*)wp;
+    float* lat_part = (float*)wp;          wp += a256(latent_part_bytes(vw, P));
+    uint8_t* lat_q = wp;                   // [scale words (256 B)][fixed-point maps], latent_q_bytes
     const bool want_p = d_xyz || d_z;
     bool want_lat = false;
     LatGrad lg{};
@@ -1636,10 +1690,38 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         lg.p[0] = nullptr;
         want_lat = false;
     }
+    const bool fixed_point = want_lat && L > 0 && latent_q_bytes(vw) > 0;
+    if (fixed_point) {
+        // larger / multi-level maps: the taps are summed with 64-bit fixed-point integer atomics (order-independent, so
+        // bit-reproducible) into workspace copies of the maps, scaled by the gradient's own magnitude, and added to d_latent
+        // by k_latq_finalize.  (Round 3 summed fp32 atomics in arrival order.)
+        unsigned* max_bits = (unsigned*)lat_q;
+        int* scale_bits = (int*)(lat_q + 64);
+        long long* q = (long long*)(lat_q + 256);
+        PNR_HIP_CHECK(hipMemsetAsync(lat_q, 0, latent_q_bytes(vw), s));
+        hipLaunchKernelGGL(k_abs_max_cols, dim3(1024), dim3(256), 0, s, dzx, MV, E, L, max_bits);
+        PNR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_latq_scale, dim3(1), dim3(1), 0, s, max_bits, (long long)(4 * MV), scale_bits);
+        PNR_LAUNCH_CHECK();
+        lg.scale_bits = scale_bits;
+        for (int l = 0; l < vw->n_levels; ++l) {
+            const uint64_t n = (uint64_t)vw->n_objs * vw->n_views * vw->lat_c[l] * vw->lat_h[l] * vw->lat_w[l];
+            lg.q[l] = lg.p[l] ? q : nullptr;
+            q += n;
+        }
+    }
     if (want_p || (want_lat && L > 0)) {
         hipLaunchKernelGGL(k_features_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, *vw, src, P, pts_per_obj, L, Din,
                            prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, dzx, E, lg, d_xyz, d_z);
         PNR_LAUNCH_CHECK();
+    }
+    if (fixed_point) {
+        for (int l = 0; l < vw->n_levels; ++l) {
+            if (!lg.q[l]) continue;
+            const int64_t n = (int64_t)vw->n_objs * vw->n_views * vw->lat_c[l] * vw->lat_h[l] * vw->lat_w[l];
+            hipLaunchKernelGGL(k_latq_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lg.q[l], n, lg.scale_bits, lg.p[l]);
+            PNR_LAUNCH_CHECK();
+        }
     }
     return PNR_OK;
 }

@@ -371,6 +371,46 @@ def test_latent_map_gradients_are_run_to_run_identical(NS, SB, lat):
     assert a.shape == base[0].shape
 
 
+@pytest.mark.parametrize("NS,SB,lat,cv,tiny_loss", [
+    (3, 1, [(256, 19, 25)], False, False),                                            # BASELINE cfg 4's map (DTU)
+    (2, 1, [(64, 32, 32), (64, 32, 32), (128, 16, 16), (256, 8, 8)], True, False),    # four levels (cfg 5 with the first pool)
+    (2, 2, [(256, 19, 25)], False, True),                                             # two objects; a loss scaled by 2^-30
+])
+def test_large_and_multilevel_latent_map_gradients_are_run_to_run_identical(NS, SB, lat, cv, tiny_loss):
+    """Maps beyond the LDS path (DTU's 19 x 25 x 256, every multi-scale shape): the tap contributions are summed with 64-bit
+    FIXED-POINT integer atomics into workspace copies of the maps — integer addition commutes, so the result does not depend
+    on arrival order — scaled by the gradient's own magnitude (2^-40 of its largest element), then added to d_latent.
+    The encoder's incoming gradient is bit-identical from run to run for these shapes too (round 3: fp32 atomics, sum order
+    = arrival order), still matches the reference's gradients (test_gradients_match_reference covers full_dtu_ns3 and
+    full_multiscale_ns2 through this path), and a loss 2^-30 times smaller gives exactly the 2^-30-fold gradient."""
+    spec = gu._case(seed=83, d_hidden=512, lat=lat, image=(400, 300) if len(lat) == 1 else (128, 128), focal=360.0 if len(lat) == 1 else 131.25,
+                    NS=NS, SB=SB, N=200, Kc=32, Kf=16, Kfd=8, use_code_viewdirs=cv)
+    rays_np, poses_np = gu.make_inputs(spec)
+    net = hu.build_net(spec, poses_np).train()
+    rend = hu.build_renderer(spec)
+    rend.forced_seed = 99
+    rays = torch.from_numpy(rays_np).cuda()
+    G = torch.randn(SB, 200, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    base = [torch.from_numpy(x).cuda() for x in gu.make_latents(spec)]
+
+    def run(scale=1.0):
+        maps = [m.clone().requires_grad_(True) for m in base]
+        net.encoder.set_latents(maps)
+        out = rend(net, rays)
+        ((out.fine.rgb * G).sum().add((out.coarse.rgb * G).sum()) * scale).backward()
+        return [m.grad.clone() for m in maps]
+
+    a, b = run(), run()
+    for x, y in zip(a, b):
+        assert float(x.abs().max()) > 0 and torch.equal(x, y)
+    if tiny_loss:
+        # a loss 2^-30 times smaller: every fp32 step of the backward scales exactly, and so must the fixed-point sums — their
+        # scale follows the gradient's magnitude (a fixed scale would have rounded these away)
+        c = run(2.0 ** -30)
+        for x, y in zip(a, c):
+            assert torch.equal(y * 2.0 ** 30, x)
+
+
 @pytest.mark.parametrize("name", ["full_ns1", "full_ns3", "full_multiscale_ns2", "tiny_ns2_codeview", "tiny_max_combine"])
 def test_bf16_mode_16bit_tape_gives_the_fp32_tapes_gradients_bit_for_bit(name):
     """train_precision='bf16' keeps the block inputs and fc_0 outputs on the tape as bf16 — the values its GEMMs stage
