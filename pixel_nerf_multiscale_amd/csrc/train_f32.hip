@@ -655,6 +655,120 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16(
     }
 }
 
+// ------------------------------------------------------------------ bf16 GEMM with an LDS-DMA k-loop (round 4)
+// C (M, N) = act(A (M, K)) . B (N, K)^T, both operands bf16 and ROW-CONTIGUOUS in the reduction index (the 16-bit tape's
+// activations / the bf16 gradient stream against bf16 copies of the weights, k_w_to_bf16): the forward and dX GEMMs of the
+// bf16 mode.  Same 128 x 128 tile, same MFMA (32x32x16 bf16, operands swapped), same k order and the same epilogue as
+// k_mgemm_bf16 — bit-identical results — but the tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no register
+// pass, no conversion, into a ring of four 16-KiB slots with THREE k-steps in flight per workgroup instead of one.
+// k_mgemm_bf16's loop issues tile i + 2 only after staging tile i + 1 through registers: one tile of loads in flight, and
+// the activation rows (64 B out of every 1-KiB row per k-step, ~100 MB working set over the chip) come from beyond the L2,
+// so every iteration paid a loaded memory latency (profiles/r04_train_gemms.txt).
+// LDS image of a tile: [128 rows][4 chunks of 16 B], chunk c of row r at r*64 + 16*(c ^ ((r >> 3) & 3)): with ds_read_b128's
+// lane groups ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) the 16 rows of a group then fall on 16 different bank
+// quads.  An LDS-DMA piece is lane-linear (lane l -> base + 16 l = row l >> 2, physical chunk l & 3), so the swizzle is on the
+// SOURCE address.  A wave issues 4 pieces per k-step (waves 0, 1: the A tile, waves 2, 3: the B tile).
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <bool RELU_A, bool M16>
+static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const void* __restrict__ Mk, int ldm, float* C, int ldc, uint16_t* __restrict__ C16, int ldc16,
+    int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 16384];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx, by, bz;
+    if (!mgemm_tile<false>(M, N, K, 0, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    // ---- loader: this wave's four pieces of a k-step (16 rows x 64 B each) of its operand
+    const bool loads_b = wv >= 2;
+    const uint16_t* src = loads_b ? B : A;
+    const int ld = loads_b ? ldb : lda, x0 = loads_b ? n0 : m0, X = loads_b ? N : M;
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * (4 * (wv & 1) + j) + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 3) & 3);
+        const int xr = x0 + row < X ? x0 + row : X - 1;            // rows past the edge re-read the last one (never stored)
+        voff[j] = (uint32_t)xr * (uint32_t)ld * 2u + 16u * c;
+    }
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
+    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+        const char* sb = (const char*)src + (size_t)ks * 64;         // 32 k = 64 B further along every row
+        const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(dst) : "memory", "scc");
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = K >> 5;
+    for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+    // fragment addresses within a slot (fixed over the loop): row r, logical chunk 2 s + lr
+    uint32_t fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const int ra = wm + 32 * i + lc, rb = wn + 32 * i + lc;
+            fa[i][sp] = (uint32_t)ra * 64u + 16u * ((2 * sp + lr) ^ ((ra >> 3) & 3));
+            fb[i][sp] = 8192u + (uint32_t)rb * 64u + 16u * ((2 * sp + lr) ^ ((rb >> 3) & 3));
+        }
+    for (int ks = 0; ks < nk; ++ks) {
+        // k-step ks has landed once at most the pieces of the (up to two) younger k-steps are outstanding (loads retire in order)
+        const int younger = nk - 1 - ks;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of k-step ks are in; slot (ks - 1) & 3 has no reader left
+        asm volatile("" ::: "memory");
+        if (ks + 3 < nk) issue(ks + 3);
+        const char* slot = ring + (ks & 3) * 16384;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            bf16x8 a0 = *(const bf16x8*)(slot + fa[0][sp]);
+            bf16x8 a1 = *(const bf16x8*)(slot + fa[1][sp]);
+            const bf16x8 b0 = *(const bf16x8*)(slot + fb[0][sp]);
+            const bf16x8 b1 = *(const bf16x8*)(slot + fb[1][sp]);
+            if (RELU_A) {       // relu on the bf16 values (sign bit set -> 0): what staging relu(fp32) and rounding gives
+                const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                a0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a0), z));
+                a1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a1), z));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+        }
+    }
+    mgemm_epilogue<false, M16>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, 0);
+}
+
+// bf16 copies of the hidden layers' weights for k_hgemm_dma: Wb = W (N, K) as stored, Wt = W^T (K, N) for the dX products
+struct W16Table { const float* w[2 * PNR_MAX_BLOCKS]; uint16_t* wb[2 * PNR_MAX_BLOCKS]; uint16_t* wt[2 * PNR_MAX_BLOCKS]; int n; };
+static __global__ void k_w_to_bf16(W16Table tb, int H) {
+    const int i = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)H * H) return;
+    const int r = (int)(e / H), c = (int)(e - (int64_t)r * H);
+    const uint16_t v = (uint16_t)(pk_bf16(tb.w[i][e], 0.f) & 0xffffu);
+    tb.wb[i][e] = v;
+    tb.wt[i][(size_t)c * H + r] = v;
+}
+
 // bf16x3: fp32-class products on the bf16 MFMA.  Every operand is split x = hi + lo (two bf16 images in LDS) and a
 // product is hi*hi + hi*lo + lo*hi (the lo*lo term is below 2^-16 relative): 3 MFMAs at 16x the fp32-MFMA rate, error
 // ~1e-5 instead of bf16's 4e-3.  Same contract and requirements as k_mgemm_bf16; single LDS buffer per image (40 KB),
@@ -1159,7 +1273,12 @@ struct Tape {
     uint16_t* A16[PNR_MAX_BLOCKS + 1];
     uint16_t* h16p[PNR_MAX_BLOCKS];
     float* xw[2];
+    // bf16 copies of fc_0 / fc_1 of every block, as stored (forward) and transposed (dX), written by the forward: the
+    // operands of k_hgemm_dma (index 2 b: fc_0, 2 b + 1: fc_1); NULL when d_hidden does not suit that kernel
+    uint16_t* Wb[2 * PNR_MAX_BLOCKS];
+    uint16_t* Wt[2 * PNR_MAX_BLOCKS];
 };
+static inline bool dma_gemm_ok(const pnr_mlp* mlp) { return mlp->d_hidden % 128 == 0; }
 
 static inline uint64_t a256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
@@ -1193,6 +1312,8 @@ static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void*
     }
     t.xpre = NS > 1 ? take((uint64_t)NS * P * H) : nullptr;
     t.o4 = take((uint64_t)P * 4);
+    if (h16 && dma_gemm_ok(mlp))
+        for (int i = 0; i < 2 * mlp->n_blocks; ++i) { t.Wb[i] = take16((uint64_t)H * H); t.Wt[i] = take16((uint64_t)H * H); }
     t.total = off + 256;
     return t;
 }
@@ -1269,7 +1390,9 @@ static inline bool al16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0
 
 // 16-bit-tape forms of a bf16-product GEMM: X16 (the activations operand as bf16, instead of X), Mk16 (the relu mask as bf16,
 // instead of Mk), Y16 (a bf16 copy of the result; Y may then be NULL).  Only the bf16 MFMA kernel takes them.
-struct G16 { const uint16_t* X16; const uint16_t* Mk16; uint16_t* Y16; };
+// W16 (with X16): a bf16 copy of the weight operand laid out (N, K) for THIS product (Tape.Wb for y = x W^T, Tape.Wt for
+// dX = dY W) — the GEMM then runs on k_hgemm_dma.
+struct G16 { const uint16_t* X16; const uint16_t* Mk16; uint16_t* Y16; const uint16_t* W16 = nullptr; };
 
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
@@ -1277,6 +1400,18 @@ static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int
     if (M == 0) return PNR_OK;
     if (!(N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(W, ldw))) return PNR_E_UNSUPPORTED;
     const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
+    if (g.X16 && g.W16 && ldx % 8 == 0 && ((uintptr_t)g.X16 & 15) == 0 && ((uintptr_t)g.W16 & 15) == 0 && !(Mk && !g.Mk16)) {
+        // both operands bf16 and row-contiguous in the reduction index: the LDS-DMA k-loop (W16 is (N, K), leading dimension K)
+        const void* Mp16 = (const void*)g.Mk16;
+        if (g.Mk16)
+            hipLaunchKernelGGL((k_hgemm_dma<RELU_X, true>), grid, dim3(256), 0, s, g.X16, ldx, g.W16, K, b, R, ldr, Mp16, ldm, Y, ldy,
+                               g.Y16, ldy, (int)M, N, K);
+        else
+            hipLaunchKernelGGL((k_hgemm_dma<RELU_X, false>), grid, dim3(256), 0, s, g.X16, ldx, g.W16, K, b, R, ldr, (const void*)nullptr,
+                               ldm, Y, ldy, g.Y16, ldy, (int)M, N, K);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     const void* Xp = g.X16 ? (const void*)g.X16 : (const void*)X;
     const void* Mp = g.Mk16 ? (const void*)g.Mk16 : (const void*)Mk;
 #define PNR_G16_LAUNCH(A16, M16)                                                                                       \
@@ -1496,6 +1631,17 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
     };
     int cur = 0;
     const bool comb0 = NS > 1 && cl == 0;
+    if (t.Wb[0]) {      // bf16 copies of the hidden weights (as stored + transposed) for the LDS-DMA GEMMs of forward and backward
+        W16Table tb{};
+        tb.n = 2 * nb;
+        for (int b = 0; b < nb; ++b) {
+            tb.w[2 * b] = mlp->fc0_w[b]; tb.w[2 * b + 1] = mlp->fc1_w[b];
+            tb.wb[2 * b] = t.Wb[2 * b]; tb.wb[2 * b + 1] = t.Wb[2 * b + 1];
+            tb.wt[2 * b] = t.Wt[2 * b]; tb.wt[2 * b + 1] = t.Wt[2 * b + 1];
+        }
+        hipLaunchKernelGGL(k_w_to_bf16, dim3((unsigned)(((int64_t)H * H + 255) / 256), (unsigned)tb.n), dim3(256), 0, s, tb, H);
+        PNR_LAUNCH_CHECK();
+    }
     // lin_in (Din is not a multiple of 32: the fp32 kernels, fp32 operand zx)
     PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, comb0 ? t.xpre : t.xw[cur], H,
                                 MV, H, Din, s, 1)));
@@ -1515,13 +1661,13 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
             }
         }
         // h = fc_0(relu(x)): operand and result live on the tape only
-        PNR_TRY((gemm16<true, false>(G16{t.A16[b], nullptr, t.h16p[b]}, nullptr, H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0,
+        PNR_TRY((gemm16<true, false>(G16{t.A16[b], nullptr, t.h16p[b], t.Wb[2 * b]}, nullptr, H, mlp->fc0_w[b], H, mlp->fc0_b[b], nullptr, 0,
                                      nullptr, 0, nullptr, H, M, H, H, s)));
         const bool comb = NS > 1 && b + 1 == cl;
         float* dst = comb ? t.xpre : t.xw[cur ^ 1];
         // x' = x + fc_1(relu(h)): fp32 for the chain, bf16 copy = the next block's input (unless lin_z / the reduction rewrite it)
         const bool next_final = !comb && !(L > 0 && b + 1 < n_lin_z);
-        PNR_TRY((gemm16<true, false>(G16{t.h16p[b], nullptr, next_final ? t.A16[b + 1] : nullptr}, nullptr, H, mlp->fc1_w[b], H,
+        PNR_TRY((gemm16<true, false>(G16{t.h16p[b], nullptr, next_final ? t.A16[b + 1] : nullptr, t.Wb[2 * b + 1]}, nullptr, H, mlp->fc1_w[b], H,
                                      mlp->fc1_b[b], x, H, nullptr, 0, dst, H, M, H, H, s)));
         cur ^= 1;
         if (comb) {
@@ -1635,10 +1781,10 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
             // of the same values: gradients stay bit-identical to the fp32-tape form; 0.76x the bytes of a block's backward.
             if (!dx16_valid) { PNR_TRY(to16(dx, M * H, dx16)); dx16_valid = true; }
             PNR_TRY((grad_w<true>(dx, H, nullptr, H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws, t.h16p[b], dx16)));
-            PNR_TRY((gemm16<false, true>(G16{dx16, t.h16p[b], dh16}, nullptr, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, nullptr, H,
+            PNR_TRY((gemm16<false, true>(G16{dx16, t.h16p[b], dh16, t.Wt[2 * b + 1]}, nullptr, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, nullptr, H,
                                          nullptr, H, M, H, H, s)));
             PNR_TRY((grad_w<true>(nullptr, H, nullptr, H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws, t.A16[b], dh16)));
-            PNR_TRY((gemm16<false, true>(G16{dh16, t.A16[b], dx16}, nullptr, H, mlp->fc0_w[b], H, nullptr, dx, H, nullptr, H, dx, H,
+            PNR_TRY((gemm16<false, true>(G16{dh16, t.A16[b], dx16, t.Wt[2 * b]}, nullptr, H, mlp->fc0_w[b], H, nullptr, dx, H, nullptr, H, dx, H,
                                          M, H, H, s)));
         } else {
         PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws)));
