@@ -757,16 +757,153 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
     mgemm_epilogue<false, M16>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, 0);
 }
 
+// The weight-gradient form of k_hgemm_dma: dW (N, K) partial of one row slice = dY (m, N)^T . act(X (m, K)), both operands bf16
+// and stored REDUCTION-major (a row = one point, the output index contiguous).  Tiles of 32 points x 128 columns go
+// global -> LDS by LDS-DMA as they are (256-byte rows, full-line reads) and the MFMA fragments — 8 consecutive points of one
+// column per lane — come out of the K-major image with gfx950's transposing LDS read (ds_read_b64_tr_b16: 4 rows x 16
+// columns per 16-lane group, delivered column-major).  Element j of a lane's fragment is reduction index 16 s + 8 lr + j,
+// exactly as in k_mgemm_bf16, so partials (and with them every weight gradient) are bit-identical to that kernel's.
+// LDS image: [32 rows][16 chunks of 16 B], chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) — the
+// swizzle that keeps both the transposed reads and row reads conflict-free on 256-byte rows (cdna_hip_programming.md T10);
+// applied on the DMA's source address.  Needs the slice bounds and M to be multiples of 32 (no zero-filled tail rows).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool RELU_B>
+static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+    float* __restrict__ rowsum, int M /* output rows (A's columns) */, int N /* output columns (B's columns) */, int Rn,
+    int r_per_split, size_t zs_c, size_t zs_r) {
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 16384];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx, by, bz;
+    if (!mgemm_tile<true>(M, N, Rn, r_per_split, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int rb = bz * r_per_split, re = min(Rn, rb + r_per_split);
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+    const bool loads_b = wv >= 2;
+    const uint16_t* src = loads_b ? B : A;
+    const int ld = loads_b ? ldb : lda, x0 = loads_b ? n0 : m0;
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (4 * (wv & 1) + j) + (lane >> 4);           // row of the 32-row tile this lane's piece slot holds
+        const int ch = (lane & 15) ^ swz(row);
+        voff[j] = (uint32_t)row * (uint32_t)ld * 2u + (uint32_t)x0 * 2u + 16u * ch;
+    }
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
+    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    const char* src_rb = (const char*)src + (size_t)rb * ld * 2;
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+        const char* sb = src_rb + (size_t)ks * 32 * ld * 2;             // 32 reduction rows further
+        const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(dst) : "memory", "scc");
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = (re - rb) >> 5;
+    for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+    // transposed-read addresses within a slot: fragment (i, s, h) = rows 16 s + 8 lr + 4 h .. + 3 of the 16-column block that
+    // holds this lane's column; lane 4 q + p of a 16-lane group supplies row q, chunk (p >> 1), 8-byte half (p & 1)
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    auto tr_addr = [&](int col0 /* first column of the 32-column fragment */, int sp, int h) -> uint32_t {
+        const int row = 16 * sp + 8 * lr + 4 * h + q;
+        const int ch = ((col0 + 16 * ((lane >> 4) & 1)) >> 3) + (pp >> 1);
+        return 256u * row + 16u * (ch ^ swz(row)) + 8u * (pp & 1);
+    };
+    uint32_t fa[2][2][2], fb[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                fa[i][sp][h] = tr_addr(wm + 32 * i, sp, h);
+                fb[i][sp][h] = 8192u + tr_addr(wn + 32 * i, sp, h);
+            }
+    float rs = 0.f;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto frag = [&](uint32_t slot_lds, const uint32_t (&ad)[2]) __attribute__((always_inline)) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_lds + ad[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_lds + ad[1]));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    for (int ks = 0; ks < nk; ++ks) {
+        const int younger = nk - 1 - ks;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + 3 < nk) issue(ks + 3);
+        const uint32_t slot_lds = ring_lds + (uint32_t)(ks & 3) * 16384u;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 a0 = frag(slot_lds, fa[0][sp]);
+            const bf16x8 a1 = frag(slot_lds, fa[1][sp]);
+            bf16x8 b0 = frag(slot_lds, fb[0][sp]);
+            bf16x8 b1 = frag(slot_lds, fb[1][sp]);
+            if (RELU_B) {
+                const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                b0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, b0), z));
+                b1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, b1), z));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        if (rowsum && by == 0 && t < 128) {       // bias gradient = sums over the points of A's column t, pairwise like k_mgemm_bf16
+            const char* slot = ring + (ks & 3) * 16384;
+#pragma unroll
+            for (int r = 0; r < 32; r += 2) {
+                const uint16_t u0 = *(const uint16_t*)(slot + 256 * r + 16 * ((t >> 3) ^ swz(r)) + 2 * (t & 7));
+                const uint16_t u1 = *(const uint16_t*)(slot + 256 * (r + 1) + 16 * ((t >> 3) ^ swz(r + 1)) + 2 * (t & 7));
+                rs += __builtin_bit_cast(float, (uint32_t)u0 << 16) + __builtin_bit_cast(float, (uint32_t)u1 << 16);
+            }
+        }
+    }
+    mgemm_epilogue<true, false>(acc, m0, n0, wm, wn, lc, lr, bz, nullptr, nullptr, 0, nullptr, 0, C, ldc, nullptr, 0, M, N, zs_c);
+    if (rowsum && by == 0 && t < 128 && m0 + t < M) rowsum[bz * zs_r + m0 + t] = rs;
+}
+
 // bf16 copies of the hidden layers' weights for k_hgemm_dma: Wb = W (N, K) as stored, Wt = W^T (K, N) for the dX products
-struct W16Table { const float* w[2 * PNR_MAX_BLOCKS]; uint16_t* wb[2 * PNR_MAX_BLOCKS]; uint16_t* wt[2 * PNR_MAX_BLOCKS]; int n; };
-static __global__ void k_w_to_bf16(W16Table tb, int H) {
+// (entry i: a (rows, cols) matrix; wt may be NULL)
+static constexpr int W16_MAX = 3 * PNR_MAX_BLOCKS;
+struct W16Table { const float* w[W16_MAX]; uint16_t* wb[W16_MAX]; uint16_t* wt[W16_MAX]; int rows[W16_MAX]; int cols[W16_MAX]; int n; };
+static __global__ void k_w_to_bf16(W16Table tb) {
     const int i = blockIdx.y;
+    const int R = tb.rows[i], Cn = tb.cols[i];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)H * H) return;
-    const int r = (int)(e / H), c = (int)(e - (int64_t)r * H);
+    if (e >= (int64_t)R * Cn) return;
+    const int r = (int)(e / Cn), c = (int)(e - (int64_t)r * Cn);
     const uint16_t v = (uint16_t)(pk_bf16(tb.w[i][e], 0.f) & 0xffffu);
     tb.wb[i][e] = v;
-    tb.wt[i][(size_t)c * H + r] = v;
+    if (tb.wt[i]) tb.wt[i][(size_t)c * R + r] = v;
+}
+// bf16 copy of the first L columns of zx (the latent part: the operand of the lin_z products)
+static __global__ void k_cols_to_bf16(const float* __restrict__ x, int64_t rows, int ld, int L, uint16_t* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per pair of columns
+    const int half = L >> 1;
+    if (i >= rows * half) return;
+    const int64_t r = i / half;
+    const int c = (int)(i - r * half) * 2;
+    const float2 v = *(const float2*)(x + r * ld + c);
+    *(uint32_t*)(y + r * L + c) = pk_bf16(v.x, v.y);
 }
 
 // bf16x3: fp32-class products on the bf16 MFMA.  Every operand is split x = hi + lo (two bf16 images in LDS) and a
@@ -839,6 +976,50 @@ static __global__ void __launch_bounds__(256) k_mgemm_bf16x3(
     if (rowsum && by == 0 && t < 128 && m0 + t < M) {
         if (SPLIT) rowsum[bz * zs_r + m0 + t] = rs;
         else atomicAdd(rowsum + m0 + t, rs);
+    }
+}
+
+// dW (N, K) += dY (M, N)^T X (M, K) for a SKINNY X (K <= 96: lin_in's 42 / 78 inputs), db (N) += column sums of dY.  fp32.
+// A block owns a row slice and 256 output rows n: thread n keeps the K accumulators of its row in registers and walks the
+// slice; the X rows (the same for every thread) are staged 32 at a time through LDS and read back as broadcasts, dY is
+// read coalesced.  HBM-bound on dY (4 N bytes per point).  Round 3 ran this product on the 128 x 128 fp32 MFMA tile kernel
+// with 42 live columns of 128 (174 us per 49152 x 512 call, 0.6 TB/s).
+template <int KMAX>
+static __global__ void __launch_bounds__(256) k_grad_w_skinny(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                              int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
+                                                              int M, int N, int K, int rows_per_split, size_t zs_w, size_t zs_b) {
+    __shared__ float Xs[32][KMAX];
+    const int t = threadIdx.x;
+    const int n = blockIdx.x * 256 + t;
+    dW += blockIdx.y * zs_w;
+    if (db) db += blockIdx.y * zs_b;
+    const int mb = blockIdx.y * rows_per_split, me = min(M, mb + rows_per_split);
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    float bs = 0.f;
+    const bool live = n < N;
+    for (int m0 = mb; m0 < me; m0 += 32) {
+        const int nr = min(32, me - m0);
+        __syncthreads();
+        for (int e = t; e < 32 * KMAX; e += 256) {
+            const int r = e / KMAX, k = e - r * KMAX;
+            Xs[r][k] = (r < nr && k < K) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
+        }
+        __syncthreads();
+        float g[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) g[r] = (live && r < nr) ? dY[(size_t)(m0 + r) * ldy + n] : 0.f;     // 32 loads in flight
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            bs += g[r];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) acc[k] = fmaf(g[r], Xs[r][k], acc[k]);
+        }
+    }
+    if (live) {
+        for (int k = 0; k < K; ++k) dW[(size_t)n * ldw + k] = acc[k];
+        if (db) db[n] = bs;
     }
 }
 
@@ -1277,8 +1458,14 @@ struct Tape {
     // operands of k_hgemm_dma (index 2 b: fc_0, 2 b + 1: fc_1); NULL when d_hidden does not suit that kernel
     uint16_t* Wb[2 * PNR_MAX_BLOCKS];
     uint16_t* Wt[2 * PNR_MAX_BLOCKS];
+    // the same for the lin_z products (forward and weight gradient): bf16 copy of zx's latent columns (rows x L) and of lin_z's
+    // weights; NULL when d_latent does not suit the kernels
+    uint16_t* z16;
+    uint16_t* Wz[PNR_MAX_BLOCKS];
+    uint16_t* Wzt[PNR_MAX_BLOCKS];       // lin_z^T (L, H): the operand of d(out)/d(latent columns) = dx . W_z
 };
 static inline bool dma_gemm_ok(const pnr_mlp* mlp) { return mlp->d_hidden % 128 == 0; }
+static inline bool dma_lin_z_ok(const pnr_mlp* mlp) { return dma_gemm_ok(mlp) && mlp->d_latent > 0 && mlp->d_latent % 128 == 0; }
 
 static inline uint64_t a256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
@@ -1314,6 +1501,11 @@ static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void*
     t.o4 = take((uint64_t)P * 4);
     if (h16 && dma_gemm_ok(mlp))
         for (int i = 0; i < 2 * mlp->n_blocks; ++i) { t.Wb[i] = take16((uint64_t)H * H); t.Wt[i] = take16((uint64_t)H * H); }
+    if (h16 && dma_lin_z_ok(mlp)) {
+        t.z16 = take16((uint64_t)NS * P * mlp->d_latent);
+        const int nz_ = mlp->combine_layer < mlp->n_blocks ? mlp->combine_layer : mlp->n_blocks;
+        for (int b = 0; b < nz_; ++b) { t.Wz[b] = take16((uint64_t)H * mlp->d_latent); t.Wzt[b] = take16((uint64_t)H * mlp->d_latent); }
+    }
     t.total = off + 256;
     return t;
 }
@@ -1508,6 +1700,23 @@ __global__ void k_reduce_parts(const float* __restrict__ part, int nz, size_t zs
     out[(size_t)r * ld + c] += acc;
 }
 
+// the weight's and the bias's partials in one launch (same fixed order per element)
+__global__ void k_reduce_parts2(const float* __restrict__ pw, const float* __restrict__ pb, int nz, size_t zs_w, size_t zs_b,
+                                float* __restrict__ dW, int ldw, int K, float* __restrict__ db) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)zs_w) {
+        float acc = 0.f;
+        for (int z = 0; z < nz; ++z) acc += pw[(size_t)z * zs_w + i];
+        const int r = (int)(i / K), c = (int)(i % K);
+        dW[(size_t)r * ldw + c] += acc;
+    } else if (i < (int64_t)(zs_w + zs_b)) {
+        const int64_t j = i - (int64_t)zs_w;
+        float acc = 0.f;
+        for (int z = 0; z < nz; ++z) acc += pb[(size_t)z * zs_b + j];
+        db[j] += acc;
+    }
+}
+
 // dW (N, K) += dY^T act(X),  db (N) += column sums of dY;  rows split over the grid, one partial slice per split,
 // ordered reduction at the end.  Either output may be NULL (a frozen parameter): the GEMM kernels need dW, so a bias-only
 // request takes k_col_sums.
@@ -1535,6 +1744,11 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     float* pw = ws.part;                 // (nz, N, K)
     auto finish = [&](int nz) -> int32_t {
         float* pb = pw + (size_t)nz * zs_w;
+        if (dW && db) {          // one launch for the weight and its bias (60 -> 40 launches per training step)
+            hipLaunchKernelGGL(k_reduce_parts2, dim3((unsigned)((zs_w + zs_b + 255) / 256)), dim3(256), 0, s, pw, pb, nz, zs_w, zs_b, dW, ldw, K, db);
+            PNR_LAUNCH_CHECK();
+            return PNR_OK;
+        }
         if (dW) {
             hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((zs_w + 255) / 256)), dim3(256), 0, s, pw, nz, zs_w, dW, ldw, N, K);
             PNR_LAUNCH_CHECK();
@@ -1560,7 +1774,34 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     if (X16 && !(use_half && half == 1)) return PNR_E_UNSUPPORTED;      // the 16-bit tape is read by the bf16 MFMA kernel only
     if (dY16 && !X16) return PNR_E_UNSUPPORTED;
     const bool head = !mfma_shape && N == 4 && ldy == 4 && ((uintptr_t)dY & 15) == 0;
-    nz = splits_for(mfma_shape ? 1024 : head ? 256 : 2048, &rows);
+    // lin_in: few input columns against d_hidden output rows — its own kernel, fp32 operands in every mode
+    const bool skinny = !RELU_X && !X16 && !dY16 && K <= 96 && N >= 64 && dY && X;
+    if (skinny) {
+        // partial slices are small (N K floats): many of them, so that the chip is filled
+        int64_t want = (M + 191) / 192;
+        int64_t cap = (int64_t)(ws.floats / (zs_w + zs_b));
+        if (cap > 1024) cap = 1024;
+        if (want > cap) want = cap;
+        if (want < 1) want = 1;
+        rows = (int)((M + want - 1) / want);
+        nz = (int)((M + rows - 1) / rows);
+        float* pbs = pw + (size_t)nz * zs_w;
+        const dim3 grid((N + 255) / 256, (unsigned)nz);
+        if (K <= 48) hipLaunchKernelGGL((k_grad_w_skinny<48>), grid, dim3(256), 0, s, dY, ldy, X, ldx, pw, K, db ? pbs : nullptr, (int)M, N, K, rows, zs_w, zs_b);
+        else hipLaunchKernelGGL((k_grad_w_skinny<96>), grid, dim3(256), 0, s, dY, ldy, X, ldx, pw, K, db ? pbs : nullptr, (int)M, N, K, rows, zs_w, zs_b);
+        PNR_LAUNCH_CHECK();
+        return finish(nz);
+    }
+    // the LDS-DMA kernel runs two workgroups per CU: 32 slices x 16 tiles of a 512 x 512 weight = one full round of the chip's
+    // 512 slots (48 slices of 1024 rows were 1.5 rounds), and a third less partial-sum traffic for k_reduce_parts
+    const bool dma_kt = use_half && X16 && dY16 && M % 32 == 0 && N % 128 == 0 && K % 128 == 0 && ldy % 8 == 0 && ldx % 8 == 0 &&
+                        (((uintptr_t)dY16 | (uintptr_t)X16) & 15) == 0;
+    int rows_dma = (int)(((M + 31) / 32 + 31) / 32 * 32);
+    if (rows_dma < 256) rows_dma = 256;
+    // (the same slices for every bf16-product weight gradient, whichever kernel and tape format: the two tape formats stay
+    // bit-identical)
+    const bool slices32 = use_half && half == 1 && M % 32 == 0;
+    nz = splits_for(slices32 ? rows_dma : mfma_shape ? 1024 : head ? 256 : 2048, &rows);
     float* pb = pw + (size_t)nz * zs_w;
     float* pbk = db ? pb : nullptr;
     if (mfma_shape) {
@@ -1570,6 +1811,9 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
             hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
+        else if (dma_kt && rows % 32 == 0)
+            hipLaunchKernelGGL((k_hgemm_dma_kt<RELU_X>), grid, dim3(256), 0, s, dY16, ldy, X16, ldx, pw, K, pbk, N, K, (int)M, rows,
+                               zs_w, zs_b);
         else if (use_half && X16 && dY16)
             hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true, true, true, false>), grid, dim3(256), 0, s,
                                (const void*)dY16, ldy, (const void*)X16, ldx, (const float*)nullptr, (const float*)nullptr, 0,
@@ -1633,14 +1877,26 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
     const bool comb0 = NS > 1 && cl == 0;
     if (t.Wb[0]) {      // bf16 copies of the hidden weights (as stored + transposed) for the LDS-DMA GEMMs of forward and backward
         W16Table tb{};
-        tb.n = 2 * nb;
         for (int b = 0; b < nb; ++b) {
             tb.w[2 * b] = mlp->fc0_w[b]; tb.w[2 * b + 1] = mlp->fc1_w[b];
             tb.wb[2 * b] = t.Wb[2 * b]; tb.wb[2 * b + 1] = t.Wb[2 * b + 1];
             tb.wt[2 * b] = t.Wt[2 * b]; tb.wt[2 * b + 1] = t.Wt[2 * b + 1];
+            tb.rows[2 * b] = tb.rows[2 * b + 1] = tb.cols[2 * b] = tb.cols[2 * b + 1] = H;
         }
-        hipLaunchKernelGGL(k_w_to_bf16, dim3((unsigned)(((int64_t)H * H + 255) / 256), (unsigned)tb.n), dim3(256), 0, s, tb, H);
+        tb.n = 2 * nb;
+        if (t.z16)
+            for (int b = 0; b < n_lin_z; ++b) {
+                tb.w[tb.n] = mlp->lin_z_w[b]; tb.wb[tb.n] = t.Wz[b]; tb.wt[tb.n] = t.Wzt[b]; tb.rows[tb.n] = H; tb.cols[tb.n] = L;
+                ++tb.n;
+            }
+        const int64_t biggest = (int64_t)H * (H > L ? H : L);
+        hipLaunchKernelGGL(k_w_to_bf16, dim3((unsigned)((biggest + 255) / 256), (unsigned)tb.n), dim3(256), 0, s, tb);
         PNR_LAUNCH_CHECK();
+        if (t.z16 && n_lin_z > 0) {
+            const int64_t n2 = MV * (L / 2);
+            hipLaunchKernelGGL(k_cols_to_bf16, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, t.zx, MV, E, L, t.z16);
+            PNR_LAUNCH_CHECK();
+        }
     }
     // lin_in (Din is not a multiple of 32: the fp32 kernels, fp32 operand zx)
     PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, comb0 ? t.xpre : t.xw[cur], H,
@@ -1653,7 +1909,10 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
         if (L > 0 && b < n_lin_z) {
             // x += lin_z[b](z): fp32 operand zx; result in place + its bf16 copy = the block input
             const G16 g{nullptr, nullptr, t.A16[b]};
-            if (L % 32 == 0 && al16(t.zx, E)) {
+            if (t.z16) {             // both operands as bf16 copies: the LDS-DMA kernel (same rounding, same sums)
+                PNR_TRY((gemm16<false, false>(G16{t.z16, nullptr, t.A16[b], t.Wz[b]}, nullptr, L, mlp->lin_z_w[b], L, mlp->lin_z_b[b], x, H,
+                                              nullptr, 0, x, H, M, H, L, s)));
+            } else if (L % 32 == 0 && al16(t.zx, E)) {
                 PNR_TRY((gemm16<false, false>(g, t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], x, H, nullptr, 0, x, H, M, H, L, s)));
             } else {
                 PNR_TRY((gemm<false, false>(t.zx, E, mlp->lin_z_w[b], L, mlp->lin_z_b[b], x, H, nullptr, 0, x, H, M, H, L, s, 1)));
@@ -1793,10 +2052,17 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half)));
         }
         if (L > 0 && b < n_lin_z) {
-            PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half, dws)));
+            if (t16 && t.z16 && dx16_valid)
+                PNR_TRY((grad_w<false>(dx, H, nullptr, L, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half, dws, t.z16, dx16)));
+            else
+                PNR_TRY((grad_w<false>(dx, H, t.zx, E, gr->lin_z_w[b], L, gr->lin_z_b[b], M, H, L, s, half, dws)));
             if (want_dz) {
-                PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
-                                           dzx, E, M, L, H, s, half)));
+                if (t16 && t.z16 && dx16_valid)
+                    PNR_TRY((gemm16<false, true>(G16{dx16, nullptr, nullptr, t.Wzt[b]}, nullptr, H, mlp->lin_z_w[b], L, nullptr,
+                                                 dz_started ? dzx : nullptr, E, nullptr, 0, dzx, E, M, L, H, s)));
+                else
+                    PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
+                                               dzx, E, M, L, H, s, half)));
                 dz_started = true;
             }
         }

@@ -436,19 +436,18 @@ def test_bf16_mode_16bit_tape_gives_the_fp32_tapes_gradients_bit_for_bit(name):
         prm.train_tape_fp32 = 1 if tape == "fp32" else 0
         v, _ = net.views_struct("fp32")
         m, _ = net.mlp_struct(net.mlp_coarse, "fp32")
-        nbytes = N.lib.pnr_train_tape_bytes_for(C.byref(prm), C.byref(m), C.byref(v), 4096 * v.n_objs)
+        nbytes = N.lib.pnr_train_tape_bytes_for(C.byref(prm), C.byref(m), C.byref(v), 65536 * v.n_objs)     # a training-sized batch
         return out.fine.rgb.detach().clone(), grads, nbytes
 
     rgb16, g16, b16 = run("auto")
     rgb32, g32, b32 = run("fp32")
     assert torch.equal(rgb16, rgb32)
     for k in g32:
-        if k.startswith("latent.") and "multiscale" in name:
-            # multi-level maps are beyond the LDS: their gradient is still scattered with atomics (sum order = arrival order)
-            assert torch.allclose(g16[k], g32[k], rtol=1e-4, atol=1e-6 * float(g32[k].abs().max())), k
-        else:
-            assert torch.equal(g16[k], g32[k]), k
+        # (multi-level latent maps included since round 4: their taps are summed in fixed point, order-independent)
+        assert torch.equal(g16[k], g32[k]), k
     if "full" in name:
-        assert b16 < 0.85 * b32       # d_hidden 512: the 16-bit tape applies (0.58x with one view; the fp32 per-view stream of a multi-view net stays)
+        # d_hidden 512: the 16-bit tape applies — 0.6x with one view; the fp32 per-view stream of a multi-view net stays, and the
+        # bf16 operand copies of round 4's LDS-DMA GEMMs (weights, latent columns) ride on the tape too
+        assert b16 < (0.75 if name == "full_ns1" else 0.95) * b32
     else:
         assert b16 <= b32
