@@ -115,7 +115,11 @@ typedef struct pnr_params {
     int32_t train_tape_fp32;     /* training with precision = PNR_BF16: 0 = 16-bit tape (block inputs and fc_0 outputs kept as
                                   * bf16 — the values the bf16-product GEMMs stage anyway: gradients are bit-identical to the
                                   * fp32 tape's), 1 = fp32 tape */
-    int32_t reserved[5];
+    int32_t park_fp32;           /* fused kernel, several source views: 0 = the per-view residual streams wait for the view
+                                  * reduction (util.combine_interleaved, util.py:466-476) in the kernel's 16-bit format — half
+                                  * the bytes, the rounding every layer input takes anyway; 1 = as fp32, the reference's
+                                  * reduction of fp32 activations (symmetric in the view order), ~3 % slower on 3-view shapes */
+    int32_t reserved[4];
 } pnr_params;
 
 /* Explicit random draws, reference order (render/nerf.py:111,135,141,158).  A NULL member (or a NULL

@@ -50,7 +50,8 @@ class pnr_params(C.Structure):
     _fields_ = [
         ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("n_fine_depth", C.c_int32), ("white_bkgd", C.c_int32),
         ("lindisp", C.c_int32), ("use_code_viewdirs", C.c_int32), ("num_freqs", C.c_int32), ("precision", C.c_int32),
-        ("depth_std", C.c_float), ("freq_factor", C.c_float), ("train_tape_fp32", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("depth_std", C.c_float), ("freq_factor", C.c_float), ("train_tape_fp32", C.c_int32), ("park_fp32", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

@@ -314,6 +314,7 @@ struct MfmaArgs {
     char* gcache;                  // (grid, 4 waves, n_cached, 16 KiB): a view's gathered lin_z images, kept for its later blocks
     int n_cached;
     int n_tiles, NS, combine_max;
+    int park32;                    // multi-view: park the per-view streams as fp32 (pnr_params.park_fp32) instead of the kernel's 16-bit format
     int S_in, SZ, n_blocks, nb1, P1, P2, btab_floats, d_in, proj, Gg;
     int ldP1, ldNS;                // the loader's stream: (P1, NS), or (NS*P1, 1) when every view has its own copy (projected)
     int use_code_viewdirs, num_freqs;
@@ -954,8 +955,8 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                 view_pass();
                 const float4* slot = slot0 + (size_t)v * 4096;
                 const uint32_t lane16 = lane_id() * 16;
-                if (DT == PNR_BF16) asm volatile(PNR_VIEWSPILL_ASM_BF16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
-                else asm volatile(PNR_VIEWSPILL_ASM_F16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16) : PNR_RESBLOCK_CLOBBERS);
+                if (DT == PNR_BF16) asm volatile(PNR_VIEWSPILL_ASM_BF16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16), "s"(a.park32) : PNR_RESBLOCK_CLOBBERS);
+                else asm volatile(PNR_VIEWSPILL_ASM_F16 : : PNR_X_TILES_IN, "s"(slot), "v"(lane16), "s"(a.park32) : PNR_RESBLOCK_CLOBBERS);
                 STAMP_ACC(4, st_t);
             }
             view_pass();
@@ -965,10 +966,10 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
             const float inv = 1.0f / (float)ns_q;
             const uint32_t lane16 = lane_id() * 16;
             if (DT == PNR_BF16)
-                asm volatile(PNR_VIEWREDUCE_ASM_BF16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
+                asm volatile(PNR_VIEWREDUCE_ASM_BF16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv), "s"(a.park32)
                              : PNR_RESBLOCK_CLOBBERS);
             else
-                asm volatile(PNR_VIEWREDUCE_ASM_F16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv)
+                asm volatile(PNR_VIEWREDUCE_ASM_F16 : PNR_X_TILES : "s"(slot0), "s"(nm1), "s"(a.combine_max), "v"(lane16), "v"(inv), "s"(a.park32)
                              : PNR_RESBLOCK_CLOBBERS);
             STAMP_ACC(5, st_t);
         } else {
@@ -1108,6 +1109,7 @@ int32_t point_mfma(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* v
     a.n_cached = cached_groups(mlp, vw);
     a.n_tiles = (int)((n_points + TILE_PTS - 1) / TILE_PTS);
     a.NS = vw->n_views; a.combine_max = mlp->combine_type == PNR_COMBINE_MAX;
+    a.park32 = prm->park_fp32 ? 1 : 0;
     a.S_in = y.S_in; a.SZ = y.SZ; a.n_blocks = y.n_blocks; a.nb1 = y.nb1; a.P1 = y.P1; a.P2 = y.P2;
     a.btab_floats = y.btab_floats; a.d_in = mlp->d_in; a.proj = proj; a.Gg = y.Gg;
     a.ldP1 = proj ? y.PV * y.P1 : y.P1; a.ldNS = proj ? 1 : vw->n_views;

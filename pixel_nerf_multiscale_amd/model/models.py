@@ -155,6 +155,12 @@ class PixelNeRFNet(torch.nn.Module):
         prm.num_freqs = int(self.code.num_freqs)
         prm.freq_factor = float(self.code.freq_factor)
         prm.precision = N.PRECISIONS[precision or self.resolved_precision()]
+        # several source views in the fused kernel: "16bit" (default) parks the per-view residual streams in the kernel's own
+        # 16-bit format until the view reduction; "fp32" parks them as they are (the reference reduces fp32 activations)
+        pp = getattr(self, "park_precision", "16bit")
+        if pp not in ("16bit", "fp32"):
+            raise ValueError(f"park_precision must be '16bit' or 'fp32', got {pp!r}")
+        prm.park_fp32 = 1 if pp == "fp32" else 0
         return prm
 
     def mlp_struct(self, mlp, precision, views=None):

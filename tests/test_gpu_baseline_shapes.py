@@ -142,3 +142,43 @@ def test_cfg1_srn_64x64_k32_fp32_path_matches_the_oracle():
         net16 = build_net(spec, poses, "cuda", p)
         o16 = rend(net16, rays.cuda())
         assert _psnr(o16.coarse.rgb.cpu(), ref["coarse"]["rgb"]) >= FLOOR_DB[p], p
+
+
+@pytest.mark.parametrize("NS", [2, 3, 4])
+@pytest.mark.parametrize("combine", ["average", "max"])
+def test_multiview_reduction_against_the_fp32_path_with_the_views_permuted(NS, combine):
+    """util.combine_interleaved (util.py:466-476) reduces fp32 activations, symmetrically in the view order.  The fused kernel
+    parks the streams of views 0 .. NS-2 in its 16-bit format (the last view's stays in registers), so the view order is
+    not symmetric in the last bits — pinned here: coarse-pass PSNR against the fp32 path for 2, 3 and 4 views, mean and max,
+    in the given order AND with the views rotated; with net.park_precision = "fp32" (pnr_params.park_fp32) the streams wait as
+    fp32 and the result is at least as close.  """
+    from hip_util import build_net, build_renderer
+    spec = dict(gu.CASES["full_ns3"])
+    spec.update(NS=NS, combine_type=combine, seed=61 + NS, Kc=48, Kf=0, Kfd=0)
+    poses = np.stack([gu.pose_spherical(25.0 * v, -20.0, spec["radius"]) for v in range(NS)])[None]
+    W, H = spec["image"]
+    g = torch.Generator().manual_seed(4)
+    tgt = gu.pose_spherical(70.0, -25.0, spec["radius"])
+    rays = torch.from_numpy(gu.pinhole_rays(tgt, W, H, spec["focal"], spec["z_near"], spec["z_far"],
+                                            torch.randperm(W * H, generator=g)[:1500].numpy()))[None].cuda()
+    lat = gu.make_latents(spec)
+
+    def render(prec, perm, park="16bit"):
+        net = build_net(spec, poses[:, perm], "cuda", prec)
+        net.encoder.set_latents([torch.from_numpy(m[perm]).cuda() for m in lat])
+        net.park_precision = park
+        rend = build_renderer(spec)
+        rend.forced_seed = 8
+        return rend(net, rays).coarse.rgb.cpu()
+
+    ident = list(range(NS))
+    rot = ident[1:] + ident[:1]
+    ref = render("fp32", ident)
+    assert maxdiff(render("fp32", rot), ref) <= 2e-5                 # the fp32 path does not care about the order
+    for p in ("fp16", "bf16"):
+        a, b = render(p, ident), render(p, rot)
+        assert _psnr(a, ref) >= FLOOR_DB[p] and _psnr(b, ref) >= FLOOR_DB[p], (p, _psnr(a, ref), _psnr(b, ref))
+        a32, b32 = render(p, ident, "fp32"), render(p, rot, "fp32")
+        assert _psnr(a32, ref) >= FLOOR_DB[p] and _psnr(b32, ref) >= FLOOR_DB[p]
+        # fp32 parks: the reduction itself is exact fp32, so rotating the views moves the render by less than the 16-bit parks do
+        assert _psnr(a32, b32) >= _psnr(a, b) - 1.0, (p, _psnr(a32, b32), _psnr(a, b))

@@ -687,13 +687,26 @@ def gen_viewspill(dt):
     same moment the stores queue on the fabric (13.4 k cycles per park with 256 workgroups against 4.7 k with 32,
     profiles/r03_park_contention.txt), so bytes are time.  The rounding is the one every layer's input already takes (the
     next reader of x is relu -> 16-bit for fc_0); fp16 saturates at +-65504 like the activations (MODE.FP16_OVFL).
-    Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v).  Writes v68-71 / v96-223 (rule R1: entry guard)."""
+    Operands: %0-%15 x tiles (pinned), %16 slot base (s64), %17 lane*16 (v), %18 fp32 park (s; pnr_params.park_fp32).
+    Writes v68-71 / v96-223 (rule R1: entry guard).
+    %18 != 0: the stream is parked as it is — fp32, 64 KiB, float4 index (4 t + q) * 64 + lane = accumulators 16 t + 4 q .. + 3,
+    stored straight from the accumulator registers — for callers that want the reference's fp32 view reduction
+    (util.combine_interleaved reduces fp32 activations) at the price of twice the parked bytes."""
     E = Emit(dt)
     e = E.e
     entry_guard(e)
     e("s_nop 15")
     e("s_nop 15")                                            # MFMA write -> accumulator read
     e("s_mov_b64 s[24:25], %16")
+    e("s_cmp_lg_u32 %18, 0")
+    e("s_cbranch_scc0 7f")
+    for t in range(16):
+        for q in range(4):
+            e(f"global_store_dwordx4 %17, a[{16 * t + 4 * q}:{16 * t + 4 * q + 3}], s[24:25]" + (f" offset:{q * 1024}" if q else "") + PARK_POLICY)
+        e("s_add_u32 s24, s24, 0x1000")
+        e("s_addc_u32 s25, s25, 0")
+    e("s_branch 8f")
+    e("7:")
     if dt == "f16":
         e("s_mov_b32 s38, 0x7bff7bff")
         e("s_mov_b32 s35, 0xfbfffbff")
@@ -713,16 +726,42 @@ def gen_viewspill(dt):
         e("s_addc_u32 s25, s25, 0")
     # No vmcnt wait: the stores read their own buffer registers (written once each), the tiles are free for the next view's
     # LIN_IN at once, and the slot is not read before the reduce — whose entry guard drains the stores.
-    e("s_nop 1")
+    e("8:")
+    e("s_nop 1")                                             # (fp32 park: a store has read its data two wait states after issue)
     return E.L
 
 
 def gen_viewreduce(dt):
     """Last view: x = reduce(slot_0 .. slot_{NS-2}, x) (mean or max) from the 16-bit parks, one pass per parked view, all 16
     tiles' loads (2 x dwordx4 each) in flight at once.  Operands: %0-%15 x (pinned), %16 slot_0 base (s64), %17 NS-1 (s),
-    %18 combine_max (s), %19 lane*16 (v), %20 1/NS (v)."""
+    %18 combine_max (s), %19 lane*16 (v), %20 1/NS (v), %21 fp32 park (s): the parked streams are fp32 (gen_viewspill)."""
     E = Emit(dt)
     e = E.e
+
+    def combine_pass32(op, scale=False):
+        """fp32 parks: a ring of ten 16-register buffers, nine tiles' loads (4 x dwordx4 each) in flight while one is combined."""
+        NB, D = 10, 9
+        buf = lambda t: 96 + 16 * (t % NB)
+
+        def loads(b):
+            for q in range(4):
+                e(f"global_load_dwordx4 v[{b + 4 * q}:{b + 4 * q + 3}], %19, s[24:25]" + (f" offset:{q * 1024}" if q else "") + REDUCE_POLICY)
+            e("s_add_u32 s24, s24, 0x1000")
+            e("s_addc_u32 s25, s25, 0")
+        for t in range(D):
+            loads(buf(t))
+        for t in range(16):
+            if t + D < 16:
+                loads(buf(t + D))
+            e(f"s_waitcnt vmcnt({4 * min(D, 15 - t)})")
+            b = buf(t)
+            for i in range(16):
+                tmp = 68 + (i & 3)
+                e(f"v_accvgpr_read_b32 v{tmp}, a{16 * t + i}")
+                e(f"{op} v{tmp}, v{tmp}, v{b + i}")
+                if scale:
+                    e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
+                e(f"v_accvgpr_write_b32 a{16 * t + i}, v{tmp}")
 
     def combine_pass(op, scale=False):
         for t in range(16):
@@ -748,36 +787,47 @@ def gen_viewreduce(dt):
                         e(f"v_mul_f32 v{tmp}, v{tmp}, %20")
                     e(f"v_accvgpr_write_b32 a{acc}, v{tmp}")
 
-    entry_guard(e)                                           # rule R1: the passes write v68-71 / v96-223
+    entry_guard(e)                                           # rule R1: the passes write v68-71 / v96-255
     e("s_nop 15")
     e("s_nop 15")
     e("s_mov_b64 s[26:27], %16")
     e("s_mov_b32 s34, %17")
-    e("s_cmp_lg_u32 %18, 0")
-    e("s_cbranch_scc1 5f")
-    e("s_cmp_eq_u32 s34, 1")                                 # ---- sum over parked views; the last pass also scales by 1/NS
-    e("s_cbranch_scc1 2f")                                   #      (same order of operations as sum-then-scale: identical bits)
-    e("1:")
-    e("s_mov_b64 s[24:25], s[26:27]")
-    combine_pass("v_add_f32")
-    e("s_add_u32 s26, s26, 0x10000")
-    e("s_addc_u32 s27, s27, 0")
-    e("s_sub_u32 s34, s34, 1")
-    e("s_cmp_lg_u32 s34, 1")
-    e("s_cbranch_scc1 1b")
-    e("2:")
-    e("s_mov_b64 s[24:25], s[26:27]")
-    combine_pass("v_add_f32", scale=True)
-    e("s_branch 6f")
-    e("5:")                                                   # ---- max over parked views
-    e("s_mov_b64 s[24:25], s[26:27]")
-    combine_pass("v_max_f32")
-    e("s_add_u32 s26, s26, 0x10000")
-    e("s_addc_u32 s27, s27, 0")
-    e("s_sub_u32 s34, s34, 1")
-    e("s_cmp_lg_u32 s34, 0")
-    e("s_cbranch_scc1 5b")
-    e("6:")
+
+    def whole_reduce(cp, base):
+        """labels base+1 .. base+6; cp = the combine pass of the park format"""
+        L1, L2, L5, L6 = base + 1, base + 2, base + 5, base + 6
+        e("s_cmp_lg_u32 %18, 0")
+        e(f"s_cbranch_scc1 {L5}f")
+        e("s_cmp_eq_u32 s34, 1")                             # ---- sum over parked views; the last pass also scales by 1/NS
+        e(f"s_cbranch_scc1 {L2}f")                           #      (same order of operations as sum-then-scale: identical bits)
+        e(f"{L1}:")
+        e("s_mov_b64 s[24:25], s[26:27]")
+        cp("v_add_f32")
+        e("s_add_u32 s26, s26, 0x10000")
+        e("s_addc_u32 s27, s27, 0")
+        e("s_sub_u32 s34, s34, 1")
+        e("s_cmp_lg_u32 s34, 1")
+        e(f"s_cbranch_scc1 {L1}b")
+        e(f"{L2}:")
+        e("s_mov_b64 s[24:25], s[26:27]")
+        cp("v_add_f32", scale=True)
+        e(f"s_branch {L6}f")
+        e(f"{L5}:")                                           # ---- max over parked views
+        e("s_mov_b64 s[24:25], s[26:27]")
+        cp("v_max_f32")
+        e("s_add_u32 s26, s26, 0x10000")
+        e("s_addc_u32 s27, s27, 0")
+        e("s_sub_u32 s34, s34, 1")
+        e("s_cmp_lg_u32 s34, 0")
+        e(f"s_cbranch_scc1 {L5}b")
+        e(f"{L6}:")
+    e("s_cmp_lg_u32 %21, 0")
+    e("s_cbranch_scc1 30f")
+    whole_reduce(combine_pass, 10)
+    e("s_branch 40f")
+    e("30:")
+    whole_reduce(combine_pass32, 20)
+    e("40:")
     e("s_nop 7")
     return E.L
 
