@@ -438,7 +438,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_card:
-            dist.init_process_group("gloo")
+            # gloo announces its connections on STDOUT (C++ side): keep the one-JSON-line contract by pointing fd 1 at stderr
+            # while the group comes up (first collective included)
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
         else:
             dist.init_process_group("nccl", device_id=device)
     scaling = args.scaling if args.scaling != "auto" else ("strong" if args.workload.startswith("dtu") else "weak")
