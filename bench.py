@@ -119,10 +119,10 @@ def pmc_traffic(workload, precision):
                 src = line.split(":", 1)[1].strip()
             if line.startswith("# dtype:"):
                 dt = line.split(":", 1)[1].strip()
-        if dt != precision:
-            return None, f"{rel} was collected in {dt}: no traffic figure for a {precision} run"
             if len(parts) >= 4 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[parts[1]] = float(parts[3].split("=")[1])
+        if dt != precision:
+            return None, f"{rel} was collected in {dt}: no traffic figure for a {precision} run"
         if src != source_hash():
             return None, f"{rel} was collected on other kernel sources ({src} vs {source_hash()}): no traffic figure for this build"
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"{rel} (committed rocprofv3 --pmc passes of this command, {build_id}, sources {src}); not measured in this run"
@@ -146,11 +146,9 @@ def pmc_clock(workload, precision):
                 src = line.split(":", 1)[1].strip()
             if line.startswith("# dtype:"):
                 dt = line.split(":", 1)[1].strip()
-        if dt != precision:
-            return None
             if len(parts) >= 4 and parts[1] in ("GRBM_GUI_ACTIVE", "KERNEL_NS"):
                 vals[parts[1]] = float(parts[3].split("=")[1])
-        if src != source_hash():
+        if dt != precision or src != source_hash():
             return None
         return vals["GRBM_GUI_ACTIVE"] / 8.0 / vals["KERNEL_NS"], vals["KERNEL_NS"]
     except Exception:
