@@ -1301,12 +1301,22 @@ static __global__ void __launch_bounds__(256) k_latent_grad_lds(
     __syncthreads();
     for (int ch = threadIdx.x; ch < C; ch += 256) {        // the owner of channel ch, points in order
         const float* dcol = dzx + ((size_t)v * P + g0) * ldz + ch;
-        for (int q = 0; q < n; ++q) {
-            const float gz = dcol[(size_t)q * ldz];
+        // sixteen points' gradients in flight (the walk itself stays in point order: one global round trip per point made
+        // this loop latency-bound, 133 us per 49152-point call)
+        for (int q0 = 0; q0 < n; q0 += 16) {
+            float gz[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float wgt = tap_w[q * 4 + i];
-                if (wgt != 0.f) acc[tap_off[q * 4 + i] * C + ch] += gz * wgt;
+            for (int j = 0; j < 16; ++j) gz[j] = (q0 + j < n) ? dcol[(size_t)(q0 + j) * ldz] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = q0 + j;
+                if (q < n) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float wgt = tap_w[q * 4 + i];
+                        if (wgt != 0.f) acc[tap_off[q * 4 + i] * C + ch] += gz[j] * wgt;
+                    }
+                }
             }
         }
     }
