@@ -757,6 +757,186 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
     mgemm_epilogue<false, M16>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, 0);
 }
 
+// ------------------------------------------------------------------ fp32 GEMM with an LDS-DMA k-loop (round 4)
+// C (M, N) = act(A (M, K)) . B (N, K)^T on v_mfma_f32_32x32x2_f32, both operands fp32 and row-contiguous in the reduction index
+// — every layer of the fp32 inference path (activations x nn.Linear weights as stored) and the taped fp32 forward.  The
+// structure of k_hgemm_dma: 128 x 128 tile, 16-deep k-steps (a 64-byte row chunk per tile row), global -> LDS by LDS-DMA
+// into four 16-KiB slots, three k-steps in flight, source-side swizzle.  What changes against k_mgemm_f32 besides the
+// pipeline is the fragment traffic: that kernel reads one float per lane and MFMA (32 ds_read_b32 per k-step); here a lane
+// reads a 16-byte chunk of its row — lanes of k-half 0 the even chunk, of k-half 1 the odd chunk of a chunk pair — and MFMA e
+// of the pair multiplies reduction indices (4 c + e, 4 c + 4 + e): 8 ds_read_b128 per k-step, every product still summed
+// exactly once (the grouping of the sum differs from k_mgemm_f32's: fp32 rounding-level differences, inside the 1e-4 / 5e-4
+// tolerances of the parity and gradient tests).
+template <bool RELU_A>
+static __global__ void __launch_bounds__(256, 2) k_sgemm_dma(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* R, int ldr, const float* __restrict__ Mk, int ldm, float* C, int ldc, int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 16384];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx, by, bz;
+    if (!mgemm_tile<false>(M, N, K, 0, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    const bool loads_b = wv >= 2;
+    const float* src = loads_b ? B : A;
+    const int ld = loads_b ? ldb : lda, x0 = loads_b ? n0 : m0, X = loads_b ? N : M;
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * (4 * (wv & 1) + j) + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 3) & 3);
+        const int xr = x0 + row < X ? x0 + row : X - 1;
+        voff[j] = (uint32_t)xr * (uint32_t)ld * 4u + 16u * c;
+    }
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
+    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+        const char* sb = (const char*)src + (size_t)ks * 64;         // 16 floats further along every row
+        const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(dst) : "memory", "scc");
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = K >> 4;
+    for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+    // fragment addresses within a slot: row r, chunk 2 cp + lr of chunk pair cp
+    uint32_t fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const int ra = wm + 32 * i + lc, rb = wn + 32 * i + lc;
+            fa[i][cp] = (uint32_t)ra * 64u + 16u * ((2 * cp + lr) ^ ((ra >> 3) & 3));
+            fb[i][cp] = 8192u + (uint32_t)rb * 64u + 16u * ((2 * cp + lr) ^ ((rb >> 3) & 3));
+        }
+    for (int ks = 0; ks < nk; ++ks) {
+        const int younger = nk - 1 - ks;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + 3 < nk) issue(ks + 3);
+        const char* slot = ring + (ks & 3) * 16384;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            float4 a0 = *(const float4*)(slot + fa[0][cp]);
+            float4 a1 = *(const float4*)(slot + fa[1][cp]);
+            const float4 b0 = *(const float4*)(slot + fb[0][cp]);
+            const float4 b1 = *(const float4*)(slot + fb[1][cp]);
+            if (RELU_A) {
+                a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
+                a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+            }
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[e], av0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[e], av0[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[e], av1[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[e], av1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    mgemm_epilogue<false, false>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, (const void*)Mk, ldm, C, ldc, nullptr, 0, M, N, 0);
+}
+
+// The weight-gradient form of k_sgemm_dma: dW (N, K) partial of one row slice = dY (m, N)^T . act(X (m, K)), fp32 operands stored
+// reduction-major.  Tiles of 16 points x 128 columns (512-byte rows) by LDS-DMA, three k-steps in flight; the fragments are
+// k_mgemm_f32's — one float per lane and MFMA, lanes of one k across consecutive columns (conflict-free without a swizzle) —
+// and so is the order of the sums: partials are that kernel's bits.  Slice bounds multiples of 16.
+template <bool RELU_B>
+static __global__ void __launch_bounds__(256, 2) k_sgemm_dma_kt(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+    float* __restrict__ rowsum, int M, int N, int Rn, int r_per_split, size_t zs_c, size_t zs_r) {
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 16384];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx, by, bz;
+    if (!mgemm_tile<true>(M, N, Rn, r_per_split, bx, by, bz)) return;
+    const int m0 = bx * 128, n0 = by * 128;
+    const int rb = bz * r_per_split, re = min(Rn, rb + r_per_split);
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    const bool loads_b = wv >= 2;
+    const float* src = loads_b ? B : A;
+    const int ld = loads_b ? ldb : lda, x0 = loads_b ? n0 : m0;
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 2 * (4 * (wv & 1) + j) + (lane >> 5);           // row of the 16-row tile (a piece = 2 rows x 512 B)
+        voff[j] = (uint32_t)row * (uint32_t)ld * 4u + (uint32_t)x0 * 4u + 16u * (lane & 31);
+    }
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
+    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    const char* src_rb = (const char*)src + (size_t)rb * ld * 4;
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+        const char* sb = src_rb + (size_t)ks * 16 * ld * 4;
+        const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(dst) : "memory", "scc");
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = (re - rb) >> 4;
+    for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+    float rs = 0.f;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int younger = nk - 1 - ks;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + 3 < nk) issue(ks + 3);
+        const float* As = (const float*)(ring + (ks & 3) * 16384);          // [16 rows][128]
+        const float* Bs = As + 2048;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = 2 * e + lr;
+            const float a0 = As[r * 128 + wm + lc], a1 = As[r * 128 + wm + 32 + lc];
+            float b0 = Bs[r * 128 + wn + lc], b1 = Bs[r * 128 + wn + 32 + lc];
+            if (RELU_B) { b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        if (rowsum && by == 0 && t < 128) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs += As[r * 128 + t];
+        }
+    }
+    mgemm_epilogue<true, false>(acc, m0, n0, wm, wn, lc, lr, bz, nullptr, nullptr, 0, nullptr, 0, C, ldc, nullptr, 0, M, N, zs_c);
+    if (rowsum && by == 0 && t < 128 && m0 + t < M) rowsum[bz * zs_r + m0 + t] = rs;
+}
+
 // The weight-gradient form of k_hgemm_dma: dW (N, K) partial of one row slice = dY (m, N)^T . act(X (m, K)), both operands bf16
 // and stored REDUCTION-major (a row = one point, the output index contiguous).  Tiles of 32 points x 128 columns go
 // global -> LDS by LDS-DMA as they are (256-byte rows, full-line reads) and the MFMA fragments — 8 consecutive points of one
@@ -894,6 +1074,16 @@ static __global__ void k_w_to_bf16(W16Table tb) {
     const uint16_t v = (uint16_t)(pk_bf16(tb.w[i][e], 0.f) & 0xffffu);
     tb.wb[i][e] = v;
     if (tb.wt[i]) tb.wt[i][(size_t)c * R + r] = v;
+}
+// fp32 transposes of a table of (rows, cols) matrices: wt (cols, rows)
+struct W32Table { const float* w[W16_MAX]; float* wt[W16_MAX]; int rows[W16_MAX]; int cols[W16_MAX]; int n; };
+static __global__ void k_w_transpose_f32(W32Table tb) {
+    const int i = blockIdx.y;
+    const int R = tb.rows[i], Cn = tb.cols[i];
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)R * Cn) return;
+    const int r = (int)(e / Cn), c = (int)(e - (int64_t)r * Cn);
+    tb.wt[i][(size_t)c * R + r] = tb.w[i][e];
 }
 // bf16 copy of the first L columns of zx (the latent part: the operand of the lin_z products)
 static __global__ void k_cols_to_bf16(const float* __restrict__ x, int64_t rows, int ld, int L, uint16_t* __restrict__ y) {
@@ -1473,6 +1663,10 @@ struct Tape {
     uint16_t* z16;
     uint16_t* Wz[PNR_MAX_BLOCKS];
     uint16_t* Wzt[PNR_MAX_BLOCKS];       // lin_z^T (L, H): the operand of d(out)/d(latent columns) = dx . W_z
+    // fp32 tape, fp32 products: W^T of every hidden weight (2 b: fc_0, 2 b + 1: fc_1) and of lin_z, written by the forward — the
+    // row-contiguous operand k_sgemm_dma wants for the dX products
+    float* Wt32[2 * PNR_MAX_BLOCKS];
+    float* Wzt32[PNR_MAX_BLOCKS];
 };
 static inline bool dma_gemm_ok(const pnr_mlp* mlp) { return mlp->d_hidden % 128 == 0; }
 static inline bool dma_lin_z_ok(const pnr_mlp* mlp) { return dma_gemm_ok(mlp) && mlp->d_latent > 0 && mlp->d_latent % 128 == 0; }
@@ -1511,6 +1705,13 @@ static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void*
     t.o4 = take((uint64_t)P * 4);
     if (h16 && dma_gemm_ok(mlp))
         for (int i = 0; i < 2 * mlp->n_blocks; ++i) { t.Wb[i] = take16((uint64_t)H * H); t.Wt[i] = take16((uint64_t)H * H); }
+    if (!h16 && H % 16 == 0) {
+        for (int i = 0; i < 2 * mlp->n_blocks; ++i) t.Wt32[i] = take((uint64_t)H * H);
+        if (mlp->d_latent > 0 && mlp->d_latent % 4 == 0) {
+            const int nz_ = mlp->combine_layer < mlp->n_blocks ? mlp->combine_layer : mlp->n_blocks;
+            for (int b = 0; b < nz_; ++b) t.Wzt32[b] = take((uint64_t)H * mlp->d_latent);
+        }
+    }
     if (h16 && dma_lin_z_ok(mlp)) {
         t.z16 = take16((uint64_t)NS * P * mlp->d_latent);
         const int nz_ = mlp->combine_layer < mlp->n_blocks ? mlp->combine_layer : mlp->n_blocks;
@@ -1629,10 +1830,18 @@ static int32_t gemm16(const G16& g, const float* X, int ldx, const float* W, int
     return PNR_OK;
 }
 
+// Wt (TRANS_W products with fp32 arithmetic only): W^T as an (N, K) row-major copy — the product then runs on k_sgemm_dma
 template <bool RELU_X, bool TRANS_W>
 static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const float* b, const float* R, int ldr,
-                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, int half = 0) {
+                    const float* Mk, int ldm, float* Y, int ldy, int64_t M, int N, int K, hipStream_t s, int half = 0,
+                    const float* Wt = nullptr) {
     if (M == 0) return PNR_OK;
+    if (TRANS_W && Wt && !half && N >= 32 && K >= 64 && K % 16 == 0 && al16(X, ldx) && ((uintptr_t)Wt & 15) == 0) {
+        const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
+        hipLaunchKernelGGL((k_sgemm_dma<RELU_X>), grid, dim3(256), 0, s, X, ldx, Wt, K, b, R, ldr, Mk, ldm, Y, ldy, (int)M, N, K);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
     if (half && N >= 32 && K >= 32 && K % 32 == 0 && N % 4 == 0 && al16(X, ldx) && al16(W, ldw)) {
         const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
         if (half == 3)
@@ -1641,6 +1850,13 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
         else
             hipLaunchKernelGGL((k_mgemm_bf16<true, !TRANS_W, RELU_X, false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R,
                                ldr, Mk, ldm, Y, ldy, (float*)nullptr, (int)M, N, K, 0);
+        PNR_LAUNCH_CHECK();
+        return PNR_OK;
+    }
+    if (!TRANS_W && !half && N >= 32 && K >= 64 && K % 16 == 0 && al16(X, ldx) && al16(W, ldw)) {
+        // fp32 products, activations x weights as stored: both operands row-contiguous in the reduction index -> LDS-DMA k-loop
+        const dim3 grid = mgemm_grid((M + 127) / 128, (N + 127) / 128);
+        hipLaunchKernelGGL((k_sgemm_dma<RELU_X>), grid, dim3(256), 0, s, X, ldx, W, ldw, b, R, ldr, Mk, ldm, Y, ldy, (int)M, N, K);
         PNR_LAUNCH_CHECK();
         return PNR_OK;
     }
@@ -1810,7 +2026,8 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     if (rows_dma < 256) rows_dma = 256;
     // (the same slices for every bf16-product weight gradient, whichever kernel and tape format: the two tape formats stay
     // bit-identical)
-    const bool slices32 = use_half && half == 1 && M % 32 == 0;
+    const bool dma32 = !use_half && !half && mfma_shape && M % 32 == 0 && N % 128 == 0 && K % 128 == 0 && al16(dY, ldy) && al16(X, ldx);
+    const bool slices32 = (use_half && half == 1 && M % 32 == 0) || dma32;        // (fp32 products on k_sgemm_dma_kt: the same grid)
     nz = splits_for(slices32 ? rows_dma : mfma_shape ? 1024 : head ? 256 : 2048, &rows);
     float* pb = pw + (size_t)nz * zs_w;
     float* pbk = db ? pb : nullptr;
@@ -1836,6 +2053,8 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
             hipLaunchKernelGGL((k_mgemm_bf16<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
+        else if (dma32 && rows % 16 == 0)
+            hipLaunchKernelGGL((k_sgemm_dma_kt<RELU_X>), grid, dim3(256), 0, s, dY, ldy, X, ldx, pw, K, pbk, N, K, (int)M, rows, zs_w, zs_b);
         else
             hipLaunchKernelGGL((k_mgemm_f32<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
@@ -1970,6 +2189,20 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
+    if (t.Wt32[0] && !half) {      // W^T of the hidden weights (and lin_z) for the backward's dX products on k_sgemm_dma
+        W32Table tb{};
+        for (int b = 0; b < nb; ++b) {
+            tb.w[2 * b] = mlp->fc0_w[b]; tb.w[2 * b + 1] = mlp->fc1_w[b];
+            tb.wt[2 * b] = t.Wt32[2 * b]; tb.wt[2 * b + 1] = t.Wt32[2 * b + 1];
+            tb.rows[2 * b] = tb.rows[2 * b + 1] = tb.cols[2 * b] = tb.cols[2 * b + 1] = H;
+        }
+        tb.n = 2 * nb;
+        if (t.Wzt32[0])
+            for (int b = 0; b < n_lin_z; ++b) { tb.w[tb.n] = mlp->lin_z_w[b]; tb.wt[tb.n] = t.Wzt32[b]; tb.rows[tb.n] = H; tb.cols[tb.n] = L; ++tb.n; }
+        const int64_t biggest = (int64_t)H * (H > L ? H : L);
+        hipLaunchKernelGGL(k_w_transpose_f32, dim3((unsigned)((biggest + 255) / 256), (unsigned)tb.n), dim3(256), 0, s, tb);
+        PNR_LAUNCH_CHECK();
+    }
     PNR_TRY((gemm<false, false>(t.zx + L, E, mlp->lin_in_w, Din, mlp->lin_in_b, nullptr, 0, nullptr, 0, x0, H, MV, H, Din, s, half)));
     auto combine = [&](float* dst) -> int32_t {
         int64_t per_view = P * H;
@@ -2057,9 +2290,9 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                                          M, H, H, s)));
         } else {
         PNR_TRY((grad_w<true>(dx, H, t.h[b], H, gr->fc1_w[b], H, gr->fc1_b[b], M, H, H, s, half, dws)));
-        PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s, half)));
+        PNR_TRY((gemm<false, true>(dx, H, mlp->fc1_w[b], H, nullptr, nullptr, 0, t.h[b], H, dh, H, M, H, H, s, half, t.Wt32[2 * b + 1])));
         PNR_TRY((grad_w<true>(dh, H, t.A[b], H, gr->fc0_w[b], H, gr->fc0_b[b], M, H, H, s, half, dws)));
-        PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half)));
+        PNR_TRY((gemm<false, true>(dh, H, mlp->fc0_w[b], H, nullptr, dx, H, t.A[b], H, dx, H, M, H, H, s, half, t.Wt32[2 * b])));
         }
         if (L > 0 && b < n_lin_z) {
             if (t16 && t.z16 && dx16_valid)
@@ -2072,7 +2305,7 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                                                  dz_started ? dzx : nullptr, E, nullptr, 0, dzx, E, M, L, H, s)));
                 else
                     PNR_TRY((gemm<false, true>(dx, H, mlp->lin_z_w[b], L, nullptr, dz_started ? dzx : nullptr, E, nullptr, 0,
-                                               dzx, E, M, L, H, s, half)));
+                                               dzx, E, M, L, H, s, half, t16 ? nullptr : t.Wzt32[b])));
                 dz_started = true;
             }
         }
