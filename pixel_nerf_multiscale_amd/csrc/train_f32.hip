@@ -690,13 +690,14 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
     for (int j = 0; j < 4; ++j) {
         const int row = 16 * (4 * (wv & 1) + j) + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 3) & 3);
-        const int xr = x0 + row < X ? x0 + row : X - 1;            // rows past the edge re-read the last one (never stored)
-        voff[j] = (uint32_t)xr * (uint32_t)ld * 2u + 16u * c;
+        const int xr = x0 + row < X ? row : X - 1 - x0;            // rows past the edge re-read the last one (never stored)
+        voff[j] = (uint32_t)xr * (uint32_t)ld * 2u + 16u * c;      // relative to the tile's first row: fits 32 bits for any M
     }
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
     const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    const char* src_tile = (const char*)src + (size_t)x0 * ld * 2;
     auto issue = [&](int ks) __attribute__((always_inline)) {
-        const char* sb = (const char*)src + (size_t)ks * 64;         // 32 k = 64 B further along every row
+        const char* sb = src_tile + (size_t)ks * 64;                 // 32 k = 64 B further along every row
         const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
@@ -786,13 +787,14 @@ static __global__ void __launch_bounds__(256, 2) k_sgemm_dma(
     for (int j = 0; j < 4; ++j) {
         const int row = 16 * (4 * (wv & 1) + j) + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 3) & 3);
-        const int xr = x0 + row < X ? x0 + row : X - 1;
-        voff[j] = (uint32_t)xr * (uint32_t)ld * 4u + 16u * c;
+        const int xr = x0 + row < X ? row : X - 1 - x0;
+        voff[j] = (uint32_t)xr * (uint32_t)ld * 4u + 16u * c;      // relative to the tile's first row
     }
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
     const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    const char* src_tile = (const char*)src + (size_t)x0 * ld * 4;
     auto issue = [&](int ks) __attribute__((always_inline)) {
-        const char* sb = (const char*)src + (size_t)ks * 64;         // 16 floats further along every row
+        const char* sb = src_tile + (size_t)ks * 64;                 // 16 floats further along every row
         const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
