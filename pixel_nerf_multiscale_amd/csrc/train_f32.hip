@@ -1180,7 +1180,7 @@ template <int KMAX>
 static __global__ void __launch_bounds__(256) k_grad_w_skinny(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                               int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
                                                               int M, int N, int K, int rows_per_split, size_t zs_w, size_t zs_b) {
-    __shared__ float Xs[32][KMAX];
+    __shared__ __attribute__((aligned(16))) float Xs[32][KMAX];      // (16-byte aligned: the broadcast reads below are ds_read_b128)
     const int t = threadIdx.x;
     const int n = blockIdx.x * 256 + t;
     dW += blockIdx.y * zs_w;
@@ -1206,11 +1206,19 @@ static __global__ void __launch_bounds__(256) k_grad_w_skinny(const float* __res
         for (int r = 0; r < 32; ++r) {
             bs += g[r];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) acc[k] = fmaf(g[r], Xs[r][k], acc[k]);
+            for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+                const float4 x4 = *(const float4*)&Xs[r][4 * k4];
+                acc[4 * k4 + 0] = fmaf(g[r], x4.x, acc[4 * k4 + 0]);
+                acc[4 * k4 + 1] = fmaf(g[r], x4.y, acc[4 * k4 + 1]);
+                acc[4 * k4 + 2] = fmaf(g[r], x4.z, acc[4 * k4 + 2]);
+                acc[4 * k4 + 3] = fmaf(g[r], x4.w, acc[4 * k4 + 3]);
+            }
         }
     }
     if (live) {
-        for (int k = 0; k < K; ++k) dW[(size_t)n * ldw + k] = acc[k];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)           // (compile-time indices: a run-time index would put acc[] into scratch)
+            if (k < K) dW[(size_t)n * ldw + k] = acc[k];
         if (db) db[n] = bs;
     }
 }
