@@ -1345,14 +1345,17 @@ struct LatGrad { float* p[PNR_MAX_LEVELS]; long long* q[PNR_MAX_LEVELS]; const i
 // max |dzx[:, :L]| as float bits (atomicMax on the bits of a non-negative float is an order-independent integer maximum)
 static __global__ void __launch_bounds__(256) k_abs_max_cols(const float* __restrict__ x, int64_t rows, int ld, int L, unsigned* __restrict__ out) {
     float m = 0.f;
+    unsigned bad = 0u;
     const int64_t n = rows * L;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / L;
         const float v = fabsf(x[r * ld + (i - r * L)]);
-        m = (v == v) ? fmaxf(m, v) : m;                       // a NaN would poison the bit comparison: it goes to the map anyway
+        if (v <= 3.4e38f) m = fmaxf(m, v);                    // finite values set the scale
+        else bad = 1u;                                        // NaN / inf: remembered in out[1], k_latq_finalize propagates it
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if (bad) atomicOr(out + 1, 1u);
 }
 // The fixed-point scale 2^s of the maps: every contribution is |g w| <= max|g| < 2^ex and a map entry sums at most n_terms of
 // them, so with s = 61 - ex - ceil(log2(n_terms)) no partial sum can leave the int64 range, and the resolution 2^-s is
@@ -1368,10 +1371,13 @@ static __global__ void k_latq_scale(const unsigned* __restrict__ max_bits, long 
     *scale_bits = sb;
 }
 // d_latent += fixed-point map * 2^-s
-static __global__ void k_latq_finalize(const long long* __restrict__ q, int64_t n, const int* __restrict__ scale_bits, float* __restrict__ out) {
+static __global__ void k_latq_finalize(const long long* __restrict__ q, int64_t n, const int* __restrict__ scale_bits,
+                                       const unsigned* __restrict__ nonfinite, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] += (float)ldexp((double)q[i], -*scale_bits);
+    // a non-finite incoming gradient has no fixed-point image: the whole map says so, as the reference's float sum would in
+    // the entries it reaches
+    out[i] += *nonfinite ? __builtin_nanf("") : (float)ldexp((double)q[i], -*scale_bits);
 }
 
 static __global__ void __launch_bounds__(256) k_features_bwd(
@@ -2384,7 +2390,8 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
         for (int l = 0; l < vw->n_levels; ++l) {
             if (!lg.q[l]) continue;
             const int64_t n = (int64_t)vw->n_objs * vw->n_views * vw->lat_c[l] * vw->lat_h[l] * vw->lat_w[l];
-            hipLaunchKernelGGL(k_latq_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lg.q[l], n, lg.scale_bits, lg.p[l]);
+            hipLaunchKernelGGL(k_latq_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lg.q[l], n, lg.scale_bits,
+                               (const unsigned*)lat_q + 1, lg.p[l]);
             PNR_LAUNCH_CHECK();
         }
     }

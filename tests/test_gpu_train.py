@@ -403,6 +403,15 @@ def test_large_and_multilevel_latent_map_gradients_are_run_to_run_identical(NS, 
     a, b = run(), run()
     for x, y in zip(a, b):
         assert float(x.abs().max()) > 0 and torch.equal(x, y)
+    if not tiny_loss:
+        # a non-finite cotangent has no fixed-point image: it must surface in the map (a NaN), not vanish in the conversion
+        Gbad = G.clone()
+        Gbad[0, 7, 1] = float("nan")
+        maps = [m.clone().requires_grad_(True) for m in base]
+        net.encoder.set_latents(maps)
+        out = rend(net, rays)
+        (out.fine.rgb * Gbad).sum().backward()
+        assert all(bool(torch.isnan(m.grad).any()) for m in maps)
     if tiny_loss:
         # a loss 2^-30 times smaller: every fp32 step of the backward scales exactly, and so must the fixed-point sums — their
         # scale follows the gradient's magnitude (a fixed scale would have rounded these away)
