@@ -676,19 +676,23 @@ __global__ void __launch_bounds__(256, 1) k_point_mfma(MfmaArgs a) {
                         const Taps tp = bilinear_taps(pu[cg] * uv_sx(a.vw, lvl), pv[cg] * uv_sy(a.vw, lvl), W, H);
                         const char* lb = a.lat[lvl] + (size_t)view_of(c, cg, v) * H * W * C * 2;
                         // 4 k-steps (16 tap loads) in flight per iteration: the loop is latency-bound on L2 otherwise
-                        for (int chb = lo + 8 * g; chb < hi; chb += 128) {
+                        for (int cbase = lo; cbase < hi; cbase += 128) {       // (cbase: wave-uniform; the lane's channels start at + 8 g)
+                            const int chb = cbase + 8 * g;
                             uint4 q[4][4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const int ch = (chb + 32 * u < hi) ? chb + 32 * u : chb;       // clamp: level widths are multiples of 32
+                                // level widths are multiples of 32: k-step u of this pass exists for the whole wave or not at all — a
+                                // 64-channel level (multi-scale) issues 8 of the 16 loads instead of re-reading k-step 0 twice more
+                                if (cbase + 32 * u < hi) {
 #pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    q[u][i] = *(const uint4*)(lb + ((size_t)tp.off[i] * C + (ch - ch0)) * 2);
+                                    for (int i = 0; i < 4; ++i)
+                                        q[u][i] = *(const uint4*)(lb + ((size_t)tp.off[i] * C + (chb + 32 * u - ch0)) * 2);
+                                }
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const int ch = chb + 32 * u;
-                                if (ch < hi) {
+                                if (cbase + 32 * u < hi) {
                                     float acc8[8];
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) acc8[j] = 0.f;

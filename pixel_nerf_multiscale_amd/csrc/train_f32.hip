@@ -2038,7 +2038,10 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     // 512 slots (48 slices of 1024 rows were 1.5 rounds), and a third less partial-sum traffic for k_reduce_parts
     const bool dma_kt = use_half && X16 && dY16 && M % 32 == 0 && N % 128 == 0 && K % 128 == 0 && ldy % 8 == 0 && ldx % 8 == 0 &&
                         (((uintptr_t)dY16 | (uintptr_t)X16) & 15) == 0;
-    int rows_dma = (int)(((M + 31) / 32 + 31) / 32 * 32);
+#ifndef PNR_DW_SLICES
+#define PNR_DW_SLICES 32
+#endif
+    int rows_dma = (int)(((M + PNR_DW_SLICES - 1) / PNR_DW_SLICES + 31) / 32 * 32);
     if (rows_dma < 256) rows_dma = 256;
     // (the same slices for every bf16-product weight gradient, whichever kernel and tape format: the two tape formats stay
     // bit-identical)
