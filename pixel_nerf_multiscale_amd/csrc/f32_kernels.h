@@ -5,6 +5,40 @@
 
 namespace pnr {
 
+// Channels-last fp32 copies of the latent maps, [view][texel][C] per level (round 4): the feature build's lanes walk the
+// channels, and in the reference's NCHW layout that is a stride of H*W floats — 64 different cache lines per load
+// instruction (k_features_f32 ran at 0.4-0.5 TB/s, bound by the texture addresser).  With the channel innermost a tap is one
+// 256-byte row.  p[0] == NULL: none (the NCHW reads stay).  Built once per call into the caller's workspace / tape.
+struct LatCL { const float* p[PNR_MAX_LEVELS]; };
+static inline uint64_t latent_cl_bytes(const pnr_views& vw) {
+    uint64_t n = 0;
+    for (int l = 0; l < vw.n_levels; ++l)
+        n += (((uint64_t)vw.n_objs * vw.n_views * vw.lat_c[l] * vw.lat_h[l] * vw.lat_w[l] * 4) + 255) & ~(uint64_t)255;
+    return n;
+}
+static __global__ void k_latent_to_cl(const float* __restrict__ src, int64_t n_views, int C, int T, float* __restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // over (view, texel, channel): coalesced stores
+    if (e >= n_views * C * T) return;
+    const int c = (int)(e % C);
+    const int64_t r = e / C;
+    const int t = (int)(r % T);
+    const int64_t v = r / T;
+    dst[e] = src[(v * C + c) * T + t];
+}
+static inline LatCL latent_cl_build(const pnr_views& vw, void* base, hipStream_t s) {
+    LatCL cl{};
+    uint8_t* p = (uint8_t*)base;
+    for (int l = 0; l < vw.n_levels; ++l) {
+        if (!vw.latent[l]) return LatCL{};
+        const int64_t nv = (int64_t)vw.n_objs * vw.n_views, n = nv * vw.lat_c[l] * vw.lat_h[l] * vw.lat_w[l];
+        hipLaunchKernelGGL(k_latent_to_cl, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vw.latent[l], nv, vw.lat_c[l],
+                           vw.lat_h[l] * vw.lat_w[l], (float*)p);
+        cl.p[l] = (const float*)p;
+        p += ((uint64_t)n * 4 + 255) & ~(uint64_t)255;
+    }
+    return cl;
+}
+
 // zx[col][0..L) = bilinear latent sample, zx[col][L..L+d_in) = pos-enc(x_rot) ++ R*viewdir
 // col = v*CH + pl for point g0+pl of the chunk and source view v (view index obj*NS+v).
 // One wave per (view, point) column: the geometry (point, camera, rotation, projection, the four taps of every level) is formed
@@ -12,7 +46,7 @@ namespace pnr {
 // walk the row, 64 consecutive elements per step (coalesced stores).  Same arithmetic per element: bit-identical rows.
 static __global__ void __launch_bounds__(256) k_features_f32(pnr_views vw, PointSrc src, int64_t g0, int CH, int64_t pts_per_obj,
                                int L, int d_in, int use_code_viewdirs, int num_freqs, float freq_factor,
-                               float* __restrict__ zx, int ldz /* row stride of zx, >= L + d_in */) {
+                               float* __restrict__ zx, int ldz /* row stride of zx, >= L + d_in */, LatCL cl) {
     const int E = L + d_in;
     const int lane = threadIdx.x & 63;
     const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -35,13 +69,23 @@ static __global__ void __launch_bounds__(256) k_features_f32(pnr_views vw, Point
     for (int lvl = 0; lvl < vw.n_levels; ++lvl) {
         const int W = vw.lat_w[lvl], H = vw.lat_h[lvl], C = vw.lat_c[lvl];
         const Taps t = bilinear_taps(u * uv_sx(vw, lvl), w * uv_sy(vw, lvl), W, H);
-        const float* base = vw.latent[lvl] + (size_t)view * C * (size_t)(H * W);
-        for (int ch = lane; ch < C; ch += 64) {
-            const float* bc = base + (size_t)ch * (size_t)(H * W);
-            float val = 0.f;
+        if (cl.p[lvl]) {          // channels-last copy: a tap is C contiguous floats (same products, same order)
+            const float* base = cl.p[lvl] + (size_t)view * (size_t)(H * W) * C;
+            for (int ch = lane; ch < C; ch += 64) {
+                float val = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) val += bc[t.off[i]] * t.w[i];
-            row[e0 + ch] = val;
+                for (int i = 0; i < 4; ++i) val += base[(size_t)t.off[i] * C + ch] * t.w[i];
+                row[e0 + ch] = val;
+            }
+        } else {
+            const float* base = vw.latent[lvl] + (size_t)view * C * (size_t)(H * W);
+            for (int ch = lane; ch < C; ch += 64) {
+                const float* bc = base + (size_t)ch * (size_t)(H * W);
+                float val = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) val += bc[t.off[i]] * t.w[i];
+                row[e0 + ch] = val;
+            }
         }
         e0 += C;
     }
@@ -65,12 +109,13 @@ static inline bool latent_width_matches(const pnr_views& vw, int L) {
     return sum == L;
 }
 static inline int32_t features_launch(const pnr_views& vw, const PointSrc& src, int64_t g0, int CH, int64_t pts_per_obj, int L, int d_in,
-                                      int use_code_viewdirs, int num_freqs, float freq_factor, float* zx, int ldz, hipStream_t s) {
+                                      int use_code_viewdirs, int num_freqs, float freq_factor, float* zx, int ldz, hipStream_t s,
+                                      LatCL cl = LatCL{}) {
     if (!latent_width_matches(vw, L)) return PNR_E_SHAPE;
     const int64_t cols = (int64_t)CH * vw.n_views;
     if (cols == 0) return PNR_OK;
     hipLaunchKernelGGL(k_features_f32, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, vw, src, g0, CH, pts_per_obj, L, d_in,
-                       use_code_viewdirs, num_freqs, freq_factor, zx, ldz);
+                       use_code_viewdirs, num_freqs, freq_factor, zx, ldz, cl);
     return PNR_OK;
 }
 

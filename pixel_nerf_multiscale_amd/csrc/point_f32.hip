@@ -23,7 +23,7 @@ static const int F32_CHUNK = 49152;
 
 uint64_t point_f32_workspace_bytes(const pnr_mlp* mlp, const pnr_views* vw) {
     uint64_t per_pt = (uint64_t)vw->n_views * (((mlp->d_latent + mlp->d_in + 3) & ~3) + 2ull * mlp->d_hidden) + 4;
-    return per_pt * F32_CHUNK * sizeof(float) + 256;
+    return per_pt * F32_CHUNK * sizeof(float) + 512 + latent_cl_bytes(*vw);      // + the channels-last latent copies of a call
 }
 
 // ResnetFC.forward (resnetfc.py:203-236) on M = CH * NS assembled rows zx (row = view * CH + point, [z | x], row stride E):
@@ -61,9 +61,13 @@ int32_t point_f32(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
     float* x = zx + (size_t)F32_CHUNK * NS * E;
     float* h = x + (size_t)F32_CHUNK * NS * H;
     float* o4 = h + (size_t)F32_CHUNK * NS * H;
+    // channels-last copies of the maps, once per call (a frame is many chunks): the feature build then reads whole rows
+    void* cl_base = (void*)(((uintptr_t)(o4 + (size_t)F32_CHUNK * 4) + 255) & ~(uintptr_t)255);
+    const LatCL cl = (L > 0 && n_points >= 4096) ? latent_cl_build(*vw, cl_base, s) : LatCL{};
+    PNR_LAUNCH_CHECK();
     for (int64_t g0 = 0; g0 < n_points; g0 += F32_CHUNK) {
         int CH = (int)((n_points - g0 < F32_CHUNK) ? (n_points - g0) : F32_CHUNK);
-        PNR_TRY(features_launch(*vw, src, g0, CH, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E, s));
+        PNR_TRY(features_launch(*vw, src, g0, CH, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, zx, E, s, cl));
         PNR_LAUNCH_CHECK();
         int32_t rc;
         if ((rc = chain_f32(mlp, zx, E, CH, NS, x, h, o4, s))) return rc;

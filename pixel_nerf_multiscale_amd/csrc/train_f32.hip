@@ -1683,6 +1683,7 @@ struct Tape {
     // row-contiguous operand k_sgemm_dma wants for the dX products
     float* Wt32[2 * PNR_MAX_BLOCKS];
     float* Wzt32[PNR_MAX_BLOCKS];
+    void* lat_cl;                        // channels-last fp32 copies of the latent maps for the feature build (latent_cl_build)
 };
 static inline bool dma_gemm_ok(const pnr_mlp* mlp) { return mlp->d_hidden % 128 == 0; }
 static inline bool dma_lin_z_ok(const pnr_mlp* mlp) { return dma_gemm_ok(mlp) && mlp->d_latent > 0 && mlp->d_latent % 128 == 0; }
@@ -1721,6 +1722,7 @@ static Tape carve_tape(const pnr_mlp* mlp, const pnr_views* vw, int64_t P, void*
     t.o4 = take((uint64_t)P * 4);
     if (h16 && dma_gemm_ok(mlp))
         for (int i = 0; i < 2 * mlp->n_blocks; ++i) { t.Wb[i] = take16((uint64_t)H * H); t.Wt[i] = take16((uint64_t)H * H); }
+    if (mlp->d_latent > 0) { t.lat_cl = (void*)(p + off); off += latent_cl_bytes(*vw); }
     if (!h16 && H % 16 == 0) {
         for (int i = 0; i < 2 * mlp->n_blocks; ++i) t.Wt32[i] = take((uint64_t)H * H);
         if (mlp->d_latent > 0 && mlp->d_latent % 4 == 0) {
@@ -2107,7 +2109,8 @@ static int32_t point_train_fwd_tape16(const pnr_params* prm, const pnr_mlp* mlp,
     const int n_lin_z = cl < nb ? cl : nb;
     const int64_t MV = (int64_t)NS * P;
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
-    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s));
+    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s,
+                            (t.lat_cl && P >= 4096) ? latent_cl_build(*vw, t.lat_cl, s) : LatCL{}));
     PNR_LAUNCH_CHECK();
     auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
         hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
@@ -2204,7 +2207,8 @@ int32_t point_train_fwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_vie
     if (MV > 0x7fffffff) return PNR_E_SHAPE;
     // GEMM products: 0 = fp32 MFMA, 1 = bf16 MFMA, 3 = bf16x3 split (fp32-class) — all on the fp32 tape
     const int half = prm->precision == PNR_BF16 ? 1 : prm->precision == PNR_BF16X3 ? 3 : 0;
-    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s));
+    PNR_TRY(features_launch(*vw, src, 0, (int)P, pts_per_obj, L, Din, prm->use_code_viewdirs, prm->num_freqs, prm->freq_factor, t.zx, E, s,
+                            (t.lat_cl && P >= 4096) ? latent_cl_build(*vw, t.lat_cl, s) : LatCL{}));
     PNR_LAUNCH_CHECK();
     const bool comb0 = NS > 1 && cl == 0;
     float* x0 = comb0 ? t.xpre : t.A[0];
