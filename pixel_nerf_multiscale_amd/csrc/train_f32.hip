@@ -366,6 +366,89 @@ __device__ __forceinline__ void mgemm_epilogue(const f32x16 (&acc)[2][2], int m0
     }
 }
 
+// The same epilogue through LDS, for the kernels whose 64-KiB ring is free once the k-loop is done (k_hgemm_dma, k_sgemm_dma).
+// mgemm_epilogue's accesses follow the accumulator layout — a lane owns a ROW, so one memory instruction touches 32 rows with
+// 16-32 bytes each — and that was more than half of those launches (forward 69 -> 32 us, dX 86 -> 26 us with the epilogue
+// compiled out: profiles/r04_hgemm_epilogue.txt).  Here the accumulators go to LDS as a [128][128] fp32 tile (16-byte chunk c of
+// row r at 16 (c ^ (r & 31)): the transposed writes and the row-wise reads are both conflict-free), and a half-wave then owns
+// one 512-byte ROW SEGMENT: the mask, the residual, C and the bf16 copy move as whole 128-byte lines.  Same values, same
+// operations in the same order per element (acc + bias, mask, + residual, round) — bit-identical to mgemm_epilogue.
+// Requires the vector conditions of mgemm_epilogue and N % 4 == 0 (tile_epilogue_ok); every thread of the block calls it.
+__device__ __forceinline__ bool tile_epilogue_ok(const float* bias, const float* R, int ldr, const void* Mk, int ldm, bool m16,
+                                                 const float* C, int ldc, const uint16_t* C16, int ldc16, int N) {
+    return ((ldc | ldr | ldm | ldc16 | N) & 3) == 0 && (((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) == 0 &&
+           ((uintptr_t)Mk & (m16 ? 7 : 15)) == 0 && ((uintptr_t)C16 & 7) == 0;
+}
+template <bool M16>
+__device__ __forceinline__ void tile_epilogue_lds(const f32x16 (&acc)[2][2], char* tile, int t, int m0, int n0, int wm, int wn, int lc,
+                                                  int lr, const float* __restrict__ bias, const float* R, int ldr,
+                                                  const void* __restrict__ Mk, int ldm, float* C, int ldc,
+                                                  uint16_t* __restrict__ C16, int ldc16, int M, int N) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // no wave reads a ring slot any more (the last k-step's DMA was waited for)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = wm + 32 * i + lc, ch = (wn + 32 * j + 8 * q + 4 * lr) >> 2;
+                *(float4*)(tile + row * 512 + 16 * (ch ^ (row & 31))) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+    __syncthreads();
+    const int c = t & 31, n = n0 + 4 * c, r0 = t >> 5;
+    if (n >= N) return;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *(const float4*)(bias + n);
+#pragma unroll
+    for (int it0 = 0; it0 < 16; it0 += 4) {
+        float4 rv[4];
+        uint2 mk16[4];
+        float4 mk32[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                // the batch's global loads first: four rows in flight per thread
+            const int m = m0 + r0 + 8 * (it0 + u);
+            rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mk16[u] = make_uint2(0u, 0u);
+            mk32[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) {
+                if (R) rv[u] = *(const float4*)(R + (size_t)m * ldr + n);
+                if (Mk) {
+                    if (M16) mk16[u] = *(const uint2*)((const uint16_t*)Mk + (size_t)m * ldm + n);
+                    else mk32[u] = *(const float4*)((const float*)Mk + (size_t)m * ldm + n);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 8 * (it0 + u), m = m0 + r;
+            if (m >= M) continue;
+            const float4 a4 = *(const float4*)(tile + r * 512 + 16 * (c ^ (r & 31)));
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+            if (Mk) {
+                if (M16) {
+                    const uint16_t b16[4] = {(uint16_t)(mk16[u].x & 0xffffu), (uint16_t)(mk16[u].x >> 16), (uint16_t)(mk16[u].y & 0xffffu),
+                                             (uint16_t)(mk16[u].y >> 16)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((b16[e] & 0x8000u) == 0 && (b16[e] & 0x7fffu) != 0)) v[e] = 0.f;
+                } else {
+                    const float mk[4] = {mk32[u].x, mk32[u].y, mk32[u].z, mk32[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!(mk[e] > 0.f)) v[e] = 0.f;
+                }
+            }
+            if (R) { v[0] += rv[u].x; v[1] += rv[u].y; v[2] += rv[u].z; v[3] += rv[u].w; }
+            if (C) *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (C16) *(uint2*)(C16 + (size_t)m * ldc16 + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+        }
+    }
+}
+
 template <bool A_RC, bool B_RC, bool RELU_A, bool RELU_B, bool SPLIT>
 static __global__ void __launch_bounds__(256) k_mgemm_f32(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
@@ -695,7 +778,11 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
     }
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
     const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+#if defined(PNR_HG_DIAG) && PNR_HG_DIAG == 4
+    const char* src_tile = (const char*)src + (size_t)(x0 & 2047) * ld * 2;       // timing only: the A rows stay L2-resident
+#else
     const char* src_tile = (const char*)src + (size_t)x0 * ld * 2;
+#endif
     auto issue = [&](int ks) __attribute__((always_inline)) {
         const char* sb = src_tile + (size_t)ks * 64;                 // 32 k = 64 B further along every row
         const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
@@ -716,7 +803,9 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int nk = K >> 5;
+#if !(defined(PNR_HG_DIAG) && PNR_HG_DIAG == 2)
     for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+#endif
     // fragment addresses within a slot (fixed over the loop): row r, logical chunk 2 s + lr
     uint32_t fa[2][2], fb[2][2];
 #pragma unroll
@@ -736,8 +825,13 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's pieces of k-step ks are in; slot (ks - 1) & 3 has no reader left
         asm volatile("" ::: "memory");
+#if !(defined(PNR_HG_DIAG) && PNR_HG_DIAG == 2)
         if (ks + 3 < nk) issue(ks + 3);
+#endif
         const char* slot = ring + (ks & 3) * 16384;
+#if defined(PNR_HG_DIAG) && PNR_HG_DIAG == 3
+        continue;
+#endif
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             bf16x8 a0 = *(const bf16x8*)(slot + fa[0][sp]);
@@ -755,7 +849,13 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma(
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
         }
     }
-    mgemm_epilogue<false, M16>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, 0);
+#if defined(PNR_HG_DIAG) && PNR_HG_DIAG == 1
+    if (acc[0][0][0] != 1.2345e-31f) return;          // timing only: no epilogue
+#endif
+    if (tile_epilogue_ok(bias, R, ldr, Mk, ldm, M16, C, ldc, C16, ldc16, N))
+        tile_epilogue_lds<M16>(acc, ring, t, m0, n0, wm, wn, lc, lr, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N);
+    else
+        mgemm_epilogue<false, M16>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, Mk, ldm, C, ldc, C16, ldc16, M, N, 0);
 }
 
 // ------------------------------------------------------------------ fp32 GEMM with an LDS-DMA k-loop (round 4)
@@ -855,7 +955,10 @@ static __global__ void __launch_bounds__(256, 2) k_sgemm_dma(
             }
         }
     }
-    mgemm_epilogue<false, false>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, (const void*)Mk, ldm, C, ldc, nullptr, 0, M, N, 0);
+    if (tile_epilogue_ok(bias, R, ldr, (const void*)Mk, ldm, false, C, ldc, nullptr, 0, N))
+        tile_epilogue_lds<false>(acc, ring, t, m0, n0, wm, wn, lc, lr, bias, R, ldr, (const void*)Mk, ldm, C, ldc, nullptr, 0, M, N);
+    else
+        mgemm_epilogue<false, false>(acc, m0, n0, wm, wn, lc, lr, 0, bias, R, ldr, (const void*)Mk, ldm, C, ldc, nullptr, 0, M, N, 0);
 }
 
 // The weight-gradient form of k_sgemm_dma: dW (N, K) partial of one row slice = dY (m, N)^T . act(X (m, K)), fp32 operands stored
