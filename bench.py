@@ -517,7 +517,12 @@ def main():
         out["roofline"]["stage_kernels_hbm"] = stage_kernels_hbm(device)
         sec = []
         for wl, prec in SECONDARY:
-            r2, (spec2, net2, rend2, rays2) = time_workload(wl, prec, device, args.secondary_steps, 1)
+            try:
+                r2, (spec2, net2, rend2, rays2) = time_workload(wl, prec, device, args.secondary_steps, 1)
+            except Exception as ex:        # a secondary shape must not cost the headline line; the row says what happened
+                sec.append({"workload": wl, "dtype": prec, "error": f"{type(ex).__name__}: {ex}"[:300], "meets_8c": False})
+                torch.cuda.empty_cache()
+                continue
             e = {"workload": wl, "dtype": prec, "value": r2["value"], "unit": "rays/s", "steps": args.secondary_steps,
                  "ms_per_step": r2["ms_per_step"], "kernel": r2["roofline"]["kernel"], "kernel_ms": r2["roofline"]["kernel_ms"],
                  "peak_tflops": r2["roofline"]["peak"], "roofline_frac": r2["roofline"]["frac"],
