@@ -398,6 +398,51 @@ __device__ __forceinline__ void tile_epilogue_lds(const f32x16 (&acc)[2][2], cha
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             }
     __syncthreads();
+    if ((M16 || !Mk) && !C && !R && C16 && (N & 7) == 0 && (((uintptr_t)C16 | (uintptr_t)Mk) & 15) == 0 && ((ldc16 | ldm) & 7) == 0) {
+        // only the bf16 copy leaves (fc_0-type forward, dh of the backward): a lane takes EIGHT columns, so the copy and the
+        // mask move as 16-byte pieces (8-byte accesses run at 0.54-0.70x the 16-byte rate: MI355X_MICROARCH.md), a quarter-wave
+        // per 256-byte row segment.  Same operations per element.
+        const int c8 = t & 15, n8 = n0 + 8 * c8, rq = t >> 4;
+        if (n8 >= N) return;
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const float4 u0 = *(const float4*)(bias + n8), u1 = *(const float4*)(bias + n8 + 4);
+            bb[0] = u0.x; bb[1] = u0.y; bb[2] = u0.z; bb[3] = u0.w; bb[4] = u1.x; bb[5] = u1.y; bb[6] = u1.z; bb[7] = u1.w;
+        }
+#pragma unroll
+        for (int it0 = 0; it0 < 8; it0 += 4) {
+            uint4 mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + rq + 16 * (it0 + u);
+                mk[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (Mk && m < M) mk[u] = *(const uint4*)((const uint16_t*)Mk + (size_t)m * ldm + n8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rq + 16 * (it0 + u), m = m0 + r;
+                if (m >= M) continue;
+                const float4 a0 = *(const float4*)(tile + r * 512 + 16 * ((2 * c8) ^ (r & 31)));
+                const float4 a1 = *(const float4*)(tile + r * 512 + 16 * ((2 * c8 + 1) ^ (r & 31)));
+                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                if (bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bb[e];
+                }
+                if (Mk) {
+                    const uint32_t w[4] = {mk[u].x, mk[u].y, mk[u].z, mk[u].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t b16 = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+                        if (!((b16 & 0x8000u) == 0 && (b16 & 0x7fffu) != 0)) v[e] = 0.f;
+                    }
+                }
+                *(uint4*)(C16 + (size_t)m * ldc16 + n8) =
+                    make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
+            }
+        }
+        return;
+    }
     const int c = t & 31, n = n0 + 4 * c, r0 = t >> 5;
     if (n >= N) return;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
