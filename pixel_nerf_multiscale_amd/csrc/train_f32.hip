@@ -2058,6 +2058,53 @@ static int32_t gemm(const float* X, int ldx, const float* W, int ldw, const floa
     return PNR_OK;
 }
 
+// dX of the output head: Y (P, N) = mask(Mk > 0) (.) (X (P, 4) . W (4, N)) — four products per element, i.e. a stream: one
+// thread per four columns with its W columns in registers, a half-wave per 512-byte row segment (k_gemm_f32's 64 x 64 tile
+// stored it as 4-byte pieces at 16-byte stride: 55 us for 200 MB).  The sum is k_gemm_f32's chain (k ascending from 0), so the
+// values are that kernel's; Y16 (optional) = the bf16 copy the 16-bit-tape backward otherwise makes with k_to_bf16.
+// Needs N / 4 a power of two <= 256 (the grid stride keeps a thread on its columns) and 16-byte-aligned rows.
+static __global__ void __launch_bounds__(256) k_head_dx(const float4* __restrict__ X, const float* __restrict__ W, int ldw,
+                                                        const float* __restrict__ Mk, int ldm, float* __restrict__ Y, int ldy,
+                                                        uint16_t* __restrict__ Y16, int ldy16, int64_t P, int N) {
+    const int per_row = N >> 2;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(i0 & (per_row - 1)), n = 4 * c;
+    const int64_t row_stride = ((int64_t)gridDim.x * 256) / per_row;
+    const float4 w0 = *(const float4*)(W + n), w1 = *(const float4*)(W + (size_t)ldw + n), w2 = *(const float4*)(W + 2 * (size_t)ldw + n),
+                 w3 = *(const float4*)(W + 3 * (size_t)ldw + n);
+    const float wk[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+    for (int64_t m = i0 / per_row; m < P; m += row_stride) {
+        const float4 d = X[m];
+        const float4 mk = Mk ? *(const float4*)(Mk + (size_t)m * ldm + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float xs[4] = {d.x, d.y, d.z, d.w}, mv[4] = {mk.x, mk.y, mk.z, mk.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a = fmaf(xs[k], wk[k][j], a);
+            v[j] = (mv[j] > 0.f) ? a : 0.f;
+        }
+        *(float4*)(Y + (size_t)m * ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (Y16) *(uint2*)(Y16 + (size_t)m * ldy16 + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+    }
+}
+static bool head_dx_ok(const float* X, const float* W, int ldw, const float* Mk, int ldm, const float* Y, int ldy, int N, int K) {
+    const int per_row = N >> 2;
+    return K == 4 && N % 4 == 0 && per_row >= 1 && per_row <= 256 && (per_row & (per_row - 1)) == 0 && al16(X, 4) && al16(W, ldw) &&
+           al16(Y, ldy) && (!Mk || al16(Mk, ldm));
+}
+static int32_t head_dx(const float* X, const float* W, int ldw, const float* Mk, int ldm, float* Y, int ldy, uint16_t* Y16, int64_t P,
+                       int N, hipStream_t s) {
+    if (P == 0) return PNR_OK;
+    const int per_row = N >> 2;
+    int64_t blocks = (P * per_row + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_head_dx, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)X, W, ldw, Mk, ldm, Y, ldy, Y16, ldy, P, N);
+    PNR_LAUNCH_CHECK();
+    return PNR_OK;
+}
+
 // db (N) += column sums of dY alone: a frozen weight with a trainable bias (needs_input_grad False / True)
 __global__ void k_col_sums(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows, size_t zs_b) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2441,12 +2488,20 @@ int32_t point_bwd(const pnr_params* prm, const pnr_mlp* mlp, const pnr_views* vw
                        (const float4*)d_out, P, (float4*)do4);
     PNR_LAUNCH_CHECK();
     PNR_TRY((grad_w<true>(do4, 4, t.A[nb], H, gr->lin_out_w, H, gr->lin_out_b, P, 4, H, s, half, dws)));
-    PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s, half)));
     bool dz_started = false;
     // 16-bit tape: the fp32 dh buffer holds the two bf16 streams instead (dh, and the copy of dx)
     uint16_t* dh16 = (uint16_t*)dh;
     uint16_t* dx16 = dh16 + (size_t)MV * H;
     bool dx16_valid = false;
+    if (head_dx_ok(do4, mlp->lin_out_w, H, t.A[nb], H, dx, H, H, 4)) {
+        // the head's dX as a stream, with the gradient stream's first bf16 copy from the same pass (the head is behind the
+        // view reduction: P rows, the row count of the last block)
+        const bool copy16 = t16 && nb > 0 && t.rows[nb - 1] == P;
+        PNR_TRY(head_dx(do4, mlp->lin_out_w, H, t.A[nb], H, dx, H, copy16 ? dx16 : nullptr, P, H, s));
+        dx16_valid = copy16;
+    } else {
+        PNR_TRY((gemm<false, true>(do4, 4, mlp->lin_out_w, H, nullptr, nullptr, 0, t.A[nb], H, dx, H, P, H, 4, s, half)));
+    }
     auto to16 = [&](const float* x, int64_t n, uint16_t* y) -> int32_t {
         hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, y);
         PNR_LAUNCH_CHECK();
