@@ -1098,18 +1098,20 @@ static __global__ void __launch_bounds__(256, 2) k_sgemm_dma_kt(
 // and stored REDUCTION-major (a row = one point, the output index contiguous).  Tiles of 32 points x 128 columns go
 // global -> LDS by LDS-DMA as they are (256-byte rows, full-line reads) and the MFMA fragments — 8 consecutive points of one
 // column per lane — come out of the K-major image with gfx950's transposing LDS read (ds_read_b64_tr_b16: 4 rows x 16
-// columns per 16-lane group, delivered column-major).  Element j of a lane's fragment is reduction index 16 s + 8 lr + j,
+// columns per 16-lane group, delivered column-major).  A k-step is 64 points (two 32-KiB slots, the next one lands while this
+// one is multiplied): with 32-point k-steps in four 16-KiB slots the DMA stream with its waits and barriers alone took 38 of
+// the launch's 46 us (profiles/r04_hgemm_epilogue.txt) — half as many barriers and waits per byte now.  Element j of a lane's fragment is reduction index 16 s + 8 lr + j,
 // exactly as in k_mgemm_bf16, so partials (and with them every weight gradient) are bit-identical to that kernel's.
-// LDS image: [32 rows][16 chunks of 16 B], chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) — the
+// LDS image: [64 rows][16 chunks of 16 B], chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) — the
 // swizzle that keeps both the transposed reads and row reads conflict-free on 256-byte rows (cdna_hip_programming.md T10);
-// applied on the DMA's source address.  Needs the slice bounds and M to be multiples of 32 (no zero-filled tail rows).
+// applied on the DMA's source address.  Needs the slice bounds and M to be multiples of 64 (no zero-filled tail rows).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <bool RELU_B>
 static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
     float* __restrict__ rowsum, int M /* output rows (A's columns) */, int N /* output columns (B's columns) */, int Rn,
     int r_per_split, size_t zs_c, size_t zs_r) {
-    __shared__ __attribute__((aligned(1024))) char ring[4 * 16384];
+    __shared__ __attribute__((aligned(1024))) char ring[2 * 32768];
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     int bx, by, bz;
     if (!mgemm_tile<true>(M, N, Rn, r_per_split, bx, by, bz)) return;
@@ -1121,27 +1123,34 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
     const bool loads_b = wv >= 2;
     const uint16_t* src = loads_b ? B : A;
     const int ld = loads_b ? ldb : lda, x0 = loads_b ? n0 : m0;
-    uint32_t voff[4];
+    uint32_t voff[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 4 * (4 * (wv & 1) + j) + (lane >> 4);           // row of the 32-row tile this lane's piece slot holds
+    for (int j = 0; j < 8; ++j) {
+        const int row = 4 * (8 * (wv & 1) + j) + (lane >> 4);           // row of the 64-row tile this lane's piece slot holds
         const int ch = (lane & 15) ^ swz(row);
         voff[j] = (uint32_t)row * (uint32_t)ld * 2u + (uint32_t)x0 * 2u + 16u * ch;
     }
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
-    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 8192 : 0) + 4096 * (wv & 1));
+    const uint32_t dst0 = __builtin_amdgcn_readfirstlane(ring_lds + (loads_b ? 16384 : 0) + 8192 * (wv & 1));
     const char* src_rb = (const char*)src + (size_t)rb * ld * 2;
     auto issue = [&](int ks) __attribute__((always_inline)) {
-        const char* sb = src_rb + (size_t)ks * 32 * ld * 2;             // 32 reduction rows further
-        const uint32_t dst = dst0 + (uint32_t)(ks & 3) * 16384u;
+        const char* sb = src_rb + (size_t)ks * 64 * ld * 2;             // 64 reduction rows further
+        const uint32_t dst = dst0 + (uint32_t)(ks & 1) * 32768u;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %9\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %9\n\t"
                      "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(dst) : "memory", "scc");
+                     : "=&s"(keep)
+                     : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]),
+                       "s"(sb), "s"(dst)
+                     : "memory", "scc");
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -1150,8 +1159,8 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const int nk = (re - rb) >> 5;
-    for (int ks = 0; ks < 3 && ks < nk; ++ks) issue(ks);
+    const int nk = (re - rb) >> 6;
+    if (nk > 0) issue(0);
     // transposed-read addresses within a slot: fragment (i, s, h) = rows 16 s + 8 lr + 4 h .. + 3 of the 16-column block that
     // holds this lane's column; lane 4 q + p of a 16-lane group supplies row q, chunk (p >> 1), 8-byte half (p & 1)
     const int q = (lane & 15) >> 2, pp = lane & 3;
@@ -1160,15 +1169,15 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
         const int ch = ((col0 + 16 * ((lane >> 4) & 1)) >> 3) + (pp >> 1);
         return 256u * row + 16u * (ch ^ swz(row)) + 8u * (pp & 1);
     };
-    uint32_t fa[2][2][2], fb[2][2][2];
+    uint32_t fa[2][4][2], fb[2][4][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
+        for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 fa[i][sp][h] = tr_addr(wm + 32 * i, sp, h);
-                fb[i][sp][h] = 8192u + tr_addr(wn + 32 * i, sp, h);
+                fb[i][sp][h] = 16384u + tr_addr(wn + 32 * i, sp, h);
             }
     float rs = 0.f;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1179,17 +1188,14 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
         return __builtin_bit_cast(bf16x8, v);
     };
     for (int ks = 0; ks < nk; ++ks) {
-        const int younger = nk - 1 - ks;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of k-step ks (the only ones outstanding)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + 3 < nk) issue(ks + 3);
-        const uint32_t slot_lds = ring_lds + (uint32_t)(ks & 3) * 16384u;
+        if (ks + 1 < nk) issue(ks + 1);
+        const uint32_t slot_lds = ring_lds + (uint32_t)(ks & 1) * 32768u;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
+        for (int sp = 0; sp < 4; ++sp) {
             const bf16x8 a0 = frag(slot_lds, fa[0][sp]);
             const bf16x8 a1 = frag(slot_lds, fa[1][sp]);
             bf16x8 b0 = frag(slot_lds, fb[0][sp]);
@@ -1205,9 +1211,9 @@ static __global__ void __launch_bounds__(256, 2) k_hgemm_dma_kt(
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
         }
         if (rowsum && by == 0 && t < 128) {       // bias gradient = sums over the points of A's column t, pairwise like k_mgemm_bf16
-            const char* slot = ring + (ks & 3) * 16384;
+            const char* slot = ring + (ks & 1) * 32768;
 #pragma unroll
-            for (int r = 0; r < 32; r += 2) {
+            for (int r = 0; r < 64; r += 2) {
                 const uint16_t u0 = *(const uint16_t*)(slot + 256 * r + 16 * ((t >> 3) ^ swz(r)) + 2 * (t & 7));
                 const uint16_t u1 = *(const uint16_t*)(slot + 256 * (r + 1) + 16 * ((t >> 3) ^ swz(r + 1)) + 2 * (t & 7));
                 rs += __builtin_bit_cast(float, (uint32_t)u0 << 16) + __builtin_bit_cast(float, (uint32_t)u1 << 16);
@@ -2240,12 +2246,12 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
     }
     // the LDS-DMA kernel runs two workgroups per CU: 32 slices x 16 tiles of a 512 x 512 weight = one full round of the chip's
     // 512 slots (48 slices of 1024 rows were 1.5 rounds), and a third less partial-sum traffic for k_reduce_parts
-    const bool dma_kt = use_half && X16 && dY16 && M % 32 == 0 && N % 128 == 0 && K % 128 == 0 && ldy % 8 == 0 && ldx % 8 == 0 &&
+    const bool dma_kt = use_half && X16 && dY16 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && ldy % 8 == 0 && ldx % 8 == 0 &&
                         (((uintptr_t)dY16 | (uintptr_t)X16) & 15) == 0;
 #ifndef PNR_DW_SLICES
 #define PNR_DW_SLICES 32
 #endif
-    int rows_dma = (int)(((M + PNR_DW_SLICES - 1) / PNR_DW_SLICES + 31) / 32 * 32);
+    int rows_dma = (int)(((M + PNR_DW_SLICES - 1) / PNR_DW_SLICES + 63) / 64 * 64);
     if (rows_dma < 256) rows_dma = 256;
     // (the same slices for every bf16-product weight gradient, whichever kernel and tape format: the two tape formats stay
     // bit-identical)
@@ -2261,7 +2267,7 @@ static int32_t grad_w(const float* dY, int ldy, const float* X, int ldx, float* 
             hipLaunchKernelGGL((k_mgemm_bf16x3<false, false, false, RELU_X, true>), grid, dim3(256), 0, s, dY, ldy, X, ldx,
                                (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0, pw, K, pbk,
                                N, K, (int)M, rows, zs_w, zs_b);
-        else if (dma_kt && rows % 32 == 0)
+        else if (dma_kt && rows % 64 == 0)
             hipLaunchKernelGGL((k_hgemm_dma_kt<RELU_X>), grid, dim3(256), 0, s, dY16, ldy, X16, ldx, pw, K, pbk, N, K, (int)M, rows,
                                zs_w, zs_b);
         else if (use_half && X16 && dY16)
